@@ -1,0 +1,268 @@
+/*
+ * nvllm_attn.h -- C ABI of the MI355X (gfx950) attention hot path that drops
+ * in behind nano-vllm-rs's `attention` module.
+ *
+ * This is the boundary a Rust `extern "C"` block (compiled by build.rs with
+ * hipcc) binds.  Plain pointers and sizes only; no C++ or
+ * torch types.  Every entry cites the reference interface it replaces
+ * (paths under the reference checkout).
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers owned by the caller, laid out
+ *     exactly as the reference holds them (row-major, contiguous):
+ *        q            [batch, seq_q,  num_heads,    head_dim]
+ *        k, v         [batch, seq_kv, num_kv_heads, head_dim]
+ *        k/v cache    [num_blocks, block_size, num_kv_heads, head_dim]
+ *                     (src/core/kv_cache.rs:75-95)
+ *     GQA is native: q head h reads kv head h / (num_heads / num_kv_heads)
+ *     (src/attention/flash.rs:147-154, src/attention/paged.rs:326-338).
+ *   - Launches are asynchronous on `stream` (NULL = the default stream); no
+ *     entry point synchronises the device or allocates device memory.
+ *   - Return value: NVLLM_OK or a negative nvllm_status.  The message of the
+ *     last failure on the calling thread is nvllm_get_last_error().
+ *   - Host-logic entries (block tables, allocator, hashing) are pure CPU code
+ *     and bit-exact with the reference's integer arithmetic.
+ */
+#ifndef NVLLM_ATTN_H
+#define NVLLM_ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque HIP stream (identical to hipStream_t; declared here so that binding
+ * generators do not need the HIP headers). */
+typedef struct ihipStream_t *nvllm_stream_t;
+
+/* Mirrors crate::error::Error (src/error.rs:10-60) for the variants reachable
+ * on this path, plus launch-level failures. */
+typedef enum nvllm_status {
+    NVLLM_OK = 0,
+    NVLLM_ERR_CONFIG = -1,            /* Error::Config: shape/len mismatch, empty table        */
+    NVLLM_ERR_UNSUPPORTED = -2,       /* head_dim / block_size / T outside the built kernels   */
+    NVLLM_ERR_NULL = -3,              /* null pointer argument                                 */
+    NVLLM_ERR_HIP = -4,               /* HIP runtime / launch failure                          */
+    NVLLM_ERR_OUT_OF_BLOCKS = -5,     /* Error::OutOfBlocks                                    */
+    NVLLM_ERR_BLOCK_INDEX_OOB = -6,   /* Error::BlockIndexOutOfBounds                          */
+    NVLLM_ERR_TENSOR = -7             /* Error::Tensor: candle narrow/index_select failure     */
+} nvllm_status;
+
+/* ======================================================================== */
+/* Device kernels                                                           */
+/* ======================================================================== */
+
+/* Flash-attention prefill, bf16 in / bf16 out, f32 accumulate on MFMA.
+ * Replaces: flash_attention_forward_f16_launch (kernels/flash_attn_fwd.cu:515-534)
+ * and the CPU dispatcher flash_attention / flash_attention_cpu
+ * (src/attention/flash.rs:85-106, :137-275).
+ * Differences from the CUDA launcher, on purpose: layout is the Rust side's
+ * [B,S,H,D] (no transposes), GQA is native (num_kv_heads argument), and a
+ * status is returned.  Causal mask is TOP-LEFT aligned like flash.rs:296-306:
+ * key j is visible to query i iff j <= i.  `lse` may be NULL; otherwise
+ * [batch, num_heads, seq_q] f32 receives m + log(l) (flash_attn_fwd.cu:305-309).
+ * head_dim: 128 runs the MFMA kernel; any other head_dim <= 256 that is a
+ * multiple of 8 runs the generic kernel. */
+int nvllm_flash_attn_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse,
+                              int batch, int seq_q, int seq_kv, int num_heads, int num_kv_heads,
+                              int head_dim, float softmax_scale, int causal,
+                              nvllm_stream_t stream);
+
+/* Same contract, f32 in / f32 out (generic kernel, f32 FMA).
+ * Replaces: flash_attention_forward_f32_launch (kernels/flash_attn_fwd.cu:489-509). */
+int nvllm_flash_attn_fwd_f32(const void *q, const void *k, const void *v, void *o, float *lse,
+                             int batch, int seq_q, int seq_kv, int num_heads, int num_kv_heads,
+                             int head_dim, float softmax_scale, int causal,
+                             nvllm_stream_t stream);
+
+/* Paged attention over the block-table KV cache for a BATCH of sequences.
+ * Replaces: paged_attention (src/attention/paged.rs:117-192), which handles one
+ * sequence per call; here sequence s uses row s of `block_tables`.
+ *   q             [num_seqs, num_new_tokens, num_heads, head_dim]
+ *   block_tables  int32 [num_seqs, max_blocks_per_seq]  physical block ids
+ *                 (BlockTable::get_physical_block_ids, src/core/block.rs:251-253)
+ *   context_lens  int32 [num_seqs]  cached + new tokens (paged.rs:107); the new
+ *                 tokens' K/V must already be in the cache
+ *   out           [num_seqs, num_new_tokens, num_heads * head_dim] (paged.rs:191)
+ * When num_new_tokens > 1 the BOTTOM-RIGHT causal mask of paged.rs:357-381
+ * applies: query i sees key positions <= context_len - num_new_tokens + i.
+ * A sequence with context_len <= 0 produces zeros.  Slots past context_len in
+ * the last block are never read into the result (they may hold anything).
+ * `workspace` is split-K scratch of at least nvllm_paged_attn_workspace_bytes()
+ * bytes (may be NULL when that returns 0).
+ * bf16: head_dim 128, block_size 16, num_new_tokens * (num_heads/num_kv_heads)
+ * <= 32 run the MFMA/bandwidth kernel; other shapes run the generic kernel. */
+int nvllm_paged_attn_bf16(const void *q, const void *k_cache, const void *v_cache,
+                          const int32_t *block_tables, const int32_t *context_lens, void *out,
+                          void *workspace, size_t workspace_bytes, int num_seqs,
+                          int num_new_tokens, int num_heads, int num_kv_heads, int head_dim,
+                          int block_size, int max_blocks_per_seq, int64_t num_cache_blocks,
+                          float scale, nvllm_stream_t stream);
+
+int nvllm_paged_attn_f32(const void *q, const void *k_cache, const void *v_cache,
+                         const int32_t *block_tables, const int32_t *context_lens, void *out,
+                         void *workspace, size_t workspace_bytes, int num_seqs, int num_new_tokens,
+                         int num_heads, int num_kv_heads, int head_dim, int block_size,
+                         int max_blocks_per_seq, int64_t num_cache_blocks, float scale,
+                         nvllm_stream_t stream);
+
+/* Bytes of split-K scratch nvllm_paged_attn_* needs for this launch shape
+ * (an upper bound over all context lengths <= max_blocks_per_seq*block_size). */
+size_t nvllm_paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,
+                                        int num_kv_heads, int head_dim, int block_size,
+                                        int max_blocks_per_seq);
+
+/* KV write ("reshape_and_cache"): for each token p,
+ *   cache[slot/bs, slot%bs, :, :] = key[p, :, :]   (and value),  slot = slot_mapping[p].
+ * Replaces: write_kv_to_cache + scatter_to_cache (src/attention/paged.rs:208-320),
+ * IN PLACE (the reference returns new tensors; documented deviation).
+ *   key, value    [num_tokens, num_kv_heads, head_dim]
+ *   slot_mapping  int64 [num_tokens], from BlockTable::get_slot_mapping
+ *                 (src/core/block.rs:269-283)
+ * A negative slot skips that token; a slot >= num_cache_blocks*block_size is
+ * skipped too (never written out of bounds).  Duplicate non-negative slots in
+ * one call race; nvllm_slot_mapping_last_writer() reproduces the reference's
+ * sequential last-writer-wins by turning superseded entries into -1. */
+int nvllm_reshape_and_cache_bf16(const void *key, const void *value, void *k_cache, void *v_cache,
+                                 const int64_t *slot_mapping, int64_t num_tokens,
+                                 int num_kv_heads, int head_dim, int block_size,
+                                 int64_t num_cache_blocks, nvllm_stream_t stream);
+
+int nvllm_reshape_and_cache_f32(const void *key, const void *value, void *k_cache, void *v_cache,
+                                const int64_t *slot_mapping, int64_t num_tokens, int num_kv_heads,
+                                int head_dim, int block_size, int64_t num_cache_blocks,
+                                nvllm_stream_t stream);
+
+/* Replaces: flash_attention_get_last_error (kernels/flash_attn_fwd.cu:540-543).
+ * Thread-local; never NULL. */
+const char *nvllm_get_last_error(void);
+
+/* Replaces: flash_attention_synchronize (kernels/flash_attn_fwd.cu:548-551): 0 / -1. */
+int nvllm_synchronize(void);
+
+/* Device inventory used by the sharded launcher and the bench. */
+int nvllm_device_count(void);
+int nvllm_set_device(int device);
+
+/* ======================================================================== */
+/* Host logic: block table, slot mapping, hashing, allocator (bit-exact)     */
+/* ======================================================================== */
+
+/* compute_num_blocks (src/core/block.rs:311-313): ceil(seq_len / block_size). */
+int64_t nvllm_compute_num_blocks(int64_t seq_len, int64_t block_size);
+
+/* hash_token_block (src/core/block.rs:43-57): SipHash-1-3 (keys 0,0) over
+ * [parent_hash as u64 LE, if has_parent] ++ tokens as u32 LE. */
+uint64_t nvllm_hash_token_block(const uint32_t *token_ids, int64_t num_tokens, int has_parent,
+                                uint64_t parent_hash);
+
+/* Host-side helper for nvllm_reshape_and_cache_*: copies `slots` to `out`,
+ * replacing every entry that a LATER entry overwrites by -1, so a parallel
+ * scatter reproduces the sequential loop of paged.rs:231-262.  Returns the
+ * number of superseded entries. */
+int64_t nvllm_slot_mapping_last_writer(const int64_t *slots, int64_t n, int64_t *out);
+
+/* --- BlockTable (src/core/block.rs:183-289) ------------------------------ */
+typedef struct nvllm_block_table nvllm_block_table;
+nvllm_block_table *nvllm_block_table_new(int64_t block_size);                /* :192 */
+void nvllm_block_table_free(nvllm_block_table *t);
+int64_t nvllm_block_table_block_size(const nvllm_block_table *t);            /* :205 */
+void nvllm_block_table_append_block(nvllm_block_table *t, int64_t block_id); /* :236 */
+int64_t nvllm_block_table_num_blocks(const nvllm_block_table *t);            /* :241 */
+int nvllm_block_table_is_empty(const nvllm_block_table *t);                  /* :246 */
+void nvllm_block_table_clear(nvllm_block_table *t);                          /* :286 */
+/* :223-231; NVLLM_ERR_BLOCK_INDEX_OOB when logical_idx is not allocated. */
+int nvllm_block_table_get_block_id(const nvllm_block_table *t, int64_t logical_idx,
+                                   int64_t *block_id_out);
+/* :251; copies up to `cap` ids, returns the table length. */
+int64_t nvllm_block_table_get_physical_block_ids(const nvllm_block_table *t, int64_t *ids_out,
+                                                 int64_t cap);
+/* :269-283; writes at most `cap` slots, returns how many the table yields
+ * (positions past the last allocated block are dropped, like the reference). */
+int64_t nvllm_block_table_get_slot_mapping(const nvllm_block_table *t, int64_t seq_len,
+                                           int64_t *slots_out, int64_t cap);
+
+/* --- BlockManager (src/core/block_manager.rs:40-383) --------------------- */
+typedef struct nvllm_block_manager nvllm_block_manager;
+nvllm_block_manager *nvllm_block_manager_new(int64_t num_blocks, int64_t block_size); /* :69  */
+void nvllm_block_manager_free_handle(nvllm_block_manager *m);
+int64_t nvllm_block_manager_block_size(const nvllm_block_manager *m);                 /* :88  */
+int64_t nvllm_block_manager_num_blocks(const nvllm_block_manager *m);                 /* :93  */
+int64_t nvllm_block_manager_num_free_blocks(const nvllm_block_manager *m);            /* :98  */
+int64_t nvllm_block_manager_num_used_blocks(const nvllm_block_manager *m);            /* :103 */
+int nvllm_block_manager_has_free_blocks(const nvllm_block_manager *m);                /* :108 */
+int nvllm_block_manager_can_allocate(const nvllm_block_manager *m, int64_t n);        /* :113 */
+/* :140; NVLLM_ERR_OUT_OF_BLOCKS when the free list is empty. */
+int nvllm_block_manager_allocate(nvllm_block_manager *m, int64_t *block_id_out);
+/* :162; all-or-nothing. */
+int nvllm_block_manager_allocate_many(nvllm_block_manager *m, int64_t n, int64_t *ids_out);
+/* :187; 1 if the block went back to the free list, 0 otherwise. */
+int nvllm_block_manager_free(nvllm_block_manager *m, int64_t block_id);
+/* :215; number of blocks actually freed. */
+int64_t nvllm_block_manager_free_many(nvllm_block_manager *m, const int64_t *ids, int64_t n);
+/* get_block().ref_count() (:220, block.rs:118); -1 if the block is not in use. */
+int64_t nvllm_block_manager_ref_count(const nvllm_block_manager *m, int64_t block_id);
+/* get_block().prefix_hash() (block.rs:123); returns 1 and writes *hash_out if Some. */
+int nvllm_block_manager_prefix_hash(const nvllm_block_manager *m, int64_t block_id,
+                                    uint64_t *hash_out);
+/* :236 / :251; new ref count, or -1 for None. */
+int64_t nvllm_block_manager_increment_ref(nvllm_block_manager *m, int64_t block_id);
+int64_t nvllm_block_manager_decrement_ref(nvllm_block_manager *m, int64_t block_id);
+/* :292; block id (ref count incremented) or -1 for None. */
+int64_t nvllm_block_manager_get_cached_block(nvllm_block_manager *m, uint64_t prefix_hash);
+void nvllm_block_manager_cache_block(nvllm_block_manager *m, int64_t block_id,
+                                     uint64_t prefix_hash);                           /* :312 */
+/* :337; *was_cached_out = 1 on a prefix hit. */
+int nvllm_block_manager_allocate_with_prefix(nvllm_block_manager *m, uint64_t prefix_hash,
+                                             int64_t *block_id_out, int *was_cached_out);
+int nvllm_block_manager_is_prefix_cached(const nvllm_block_manager *m, uint64_t prefix_hash); /* :350 */
+int64_t nvllm_block_manager_num_cached_prefixes(const nvllm_block_manager *m);               /* :355 */
+void nvllm_block_manager_clear_prefix_cache(nvllm_block_manager *m);                         /* :362 */
+void nvllm_block_manager_reset(nvllm_block_manager *m);                                      /* :377 */
+
+/* ======================================================================== */
+/* Reference-shaped operators (one sequence per call, host BlockTable)       */
+/* ======================================================================== */
+
+/* paged_attention exactly as src/attention/paged.rs:117-126 takes it: one
+ * sequence, a host BlockTable, the layer's cache.  Validates like the
+ * reference (empty table -> NVLLM_ERR_CONFIG, paged.rs:133-137; batch != 1 or
+ * context_len > blocks*block_size or an id >= num_cache_blocks ->
+ * NVLLM_ERR_TENSOR), stages the table into `scratch` (device, at least
+ * nvllm_paged_attention_seq_scratch_bytes() bytes) and launches
+ * nvllm_paged_attn_*.  dtype: 0 = bf16, 1 = f32. */
+size_t nvllm_paged_attention_seq_scratch_bytes(int64_t num_table_blocks, int num_new_tokens,
+                                               int num_heads, int num_kv_heads, int head_dim,
+                                               int block_size);
+int nvllm_paged_attention_seq(const void *query, int batch, int num_new_tokens,
+                              const void *k_cache, const void *v_cache, int64_t num_cache_blocks,
+                              const nvllm_block_table *block_table, int64_t context_len,
+                              int num_heads, int num_kv_heads, int head_dim, double scale,
+                              int dtype, void *out, void *scratch, size_t scratch_bytes,
+                              nvllm_stream_t stream);
+
+/* write_kv_to_cache exactly as src/attention/paged.rs:208-215 takes it: host
+ * slot mapping (`&[usize]`), batch-1 key/value [1, seq_len, Hkv, D].
+ * slot_mapping length != seq_len -> NVLLM_ERR_CONFIG (paged.rs:218-224); a
+ * slot outside the cache -> NVLLM_ERR_TENSOR.  Duplicates resolve last-writer
+ * -wins.  `scratch` (device) needs seq_len * 8 bytes.  Updates the caches in
+ * place. */
+int nvllm_write_kv_to_cache(const void *key, const void *value, int64_t seq_len, void *k_cache,
+                            void *v_cache, int64_t num_cache_blocks, const int64_t *slot_mapping,
+                            int64_t slot_mapping_len, int block_size, int num_kv_heads,
+                            int head_dim, int dtype, void *scratch, size_t scratch_bytes,
+                            nvllm_stream_t stream);
+
+/* prefill_attention (src/attention/paged.rs:55-63): SDPA over contiguous
+ * K/V, causal mask only when causal && seq_len > 1 (:79), output flattened to
+ * [B, S, Hq*D] (:94).  Runs the flash kernel (same math, no S x S scores). */
+int nvllm_prefill_attention(const void *q, const void *k, const void *v, void *out, int batch,
+                            int seq_len, int num_heads, int num_kv_heads, int head_dim,
+                            double scale, int causal, int dtype, nvllm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVLLM_ATTN_H */

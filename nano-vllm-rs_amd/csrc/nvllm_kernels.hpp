@@ -1,0 +1,70 @@
+// nvllm_kernels.hpp -- internal launcher declarations (HIP side of the library).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace nvllm {
+namespace kernels {
+
+enum class DType : int { BF16 = 0, F32 = 1 };
+
+// K4: reshape_and_cache.hip
+hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_cache,
+                                    void *v_cache, const int64_t *slot_mapping,
+                                    int64_t num_tokens, int64_t row_bytes, int64_t num_slots,
+                                    hipStream_t stream);
+
+// K2/K2b/K3: paged_attn.hip
+struct PagedAttnArgs {
+    const void *q;
+    const void *k_cache;
+    const void *v_cache;
+    const int32_t *block_tables;
+    const int32_t *context_lens;
+    void *out;
+    void *workspace;
+    size_t workspace_bytes;
+    int num_seqs;
+    int num_new_tokens;
+    int num_heads;
+    int num_kv_heads;
+    int head_dim;
+    int block_size;
+    int max_blocks_per_seq;
+    int64_t num_cache_blocks;
+    float scale;
+};
+// true when the bandwidth (MFMA) kernel covers this shape
+bool paged_attn_fast_path(DType dt, int num_new_tokens, int num_heads, int num_kv_heads,
+                          int head_dim, int block_size);
+// split-K factor chosen for a launch shape (also sizes the workspace)
+int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq);
+size_t paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,
+                                  int num_kv_heads, int head_dim, int block_size,
+                                  int max_blocks_per_seq);
+hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream);
+
+// K1: flash_attn.hip
+struct FlashAttnArgs {
+    const void *q;
+    const void *k;
+    const void *v;
+    void *o;
+    float *lse;
+    int batch;
+    int seq_q;
+    int seq_kv;
+    int num_heads;
+    int num_kv_heads;
+    int head_dim;
+    float softmax_scale;
+    int causal;
+};
+bool flash_attn_fast_path(DType dt, const FlashAttnArgs &a);
+hipError_t launch_flash_attn(DType dt, const FlashAttnArgs &a, hipStream_t stream);
+
+}  // namespace kernels
+}  // namespace nvllm

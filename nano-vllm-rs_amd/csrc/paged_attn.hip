@@ -1,0 +1,611 @@
+// paged_attn.hip -- K2 / K2b / K3: paged attention over the block-table KV
+// cache, hand-written for gfx950 (MI355X, wave64, MFMA 16x16x32 bf16).
+//
+// Replaces paged_attention (reference src/attention/paged.rs:117-192), which
+// per sequence gathers the blocks (index_select), trims to context_len,
+// expands GQA, materialises QK^T, masks (bottom-right causal iff T > 1,
+// :357-381), softmaxes and multiplies by V -- five full copies of K and V.
+// Here K and V are read exactly once, straight from their 16-token blocks via
+// the block table, for a whole batch of sequences per launch.
+//
+// ---------------------------------------------------------------------------
+// Fast path (bf16, head_dim 128, block_size 16, T * Hq/Hkv <= 32 query rows)
+// ---------------------------------------------------------------------------
+// Roofline: HBM.  Algorithmic bytes per unit (one cached token of one sequence)
+// = 2 (K,V) * Hkv * 128 * 2 B (4 KiB at Hkv = 8); Q/O/table bytes are < 0.3 %.
+//
+// Work decomposition
+//   grid  = (splits, num_seqs, ceil(Hkv / HPB)),  block = HPB waves
+//   wave w of a workgroup owns ONE kv head and the G = Hq/Hkv query heads of
+//   its group for all T new tokens (R = T*G query rows, padded to 16 per MFMA
+//   tile), over this split's range of logical blocks.  The HPB waves of a
+//   workgroup walk the same block-table entries, so together they read the
+//   whole contiguous 16 x Hkv x 256 B block (DRAM-page friendly) while every
+//   wave keeps its own online-softmax state: no barriers, no cross-wave
+//   traffic.  Waves never share LDS; each has a private 8 KiB V staging tile.
+//
+// Per wave, per 32-token tile (two 16-token blocks):
+//   S^T[token][row] = K[token][:] . Q[row][:]      8 x mfma_f32_16x16x32_bf16
+//       A = K: lane (g = lane>>4, c = lane&15) loads 16 B of token row c at
+//       dims 32s+8g.. for k-step s -- K goes HBM -> VGPR directly in MFMA
+//       operand layout (each load instruction covers 16 rows x 64 B).
+//       B = Q^T: kept in VGPRs for the whole kernel.
+//   online softmax in the exp2 domain; state (m, l) lives in the lane that
+//       owns query row c, replicated over the four lane groups g (the row max
+//       needs two cross-group shuffles per tile; l stays a per-group partial
+//       until the end).
+//   O^T[d][row] += V^T[d][token] . P^T[token][row]  8 x mfma_f32_16x16x32_bf16
+//       B = P^T comes straight from the S^T accumulators (token 4g+j of block
+//       0/1 <-> k slot 8g + j / 8g+4+j): no lane movement.
+//       A = V^T needs tokens along k, but memory has d contiguous: V is loaded
+//       with fully coalesced 16 B/lane loads (4 whole 256 B rows per
+//       instruction), written to the wave's private LDS tile (XOR-swizzled
+//       16 B chunks) and read back transposed with ds_read_b64_tr_b16.
+//   Because O^T keeps the query row on the lane (col = lane&15), the rescale
+//   by alpha = 2^(m_old - m_new) and the final 1/l are lane-local.
+// Loads for tile i+1 are issued before tile i is consumed (register double
+// buffering, 16 KiB in flight per wave); block-table entries are fetched two
+// tiles ahead with scalar loads.  Only the last tile(s) of a sequence take
+// the masked path (context tail, bottom-right causal mask for T > 1, V rows
+// past context_len zeroed so stale cache contents can never reach O).
+//
+// Split-K (K2b): when splits > 1 every (seq, split, row) writes an
+// unnormalised partial (O[128] f32, m, l) to the workspace and
+// paged_attn_merge_kernel combines them with the usual log-sum-exp weights.
+//
+// ---------------------------------------------------------------------------
+// Generic path (any head_dim <= 256, any block_size, bf16 or f32)
+// ---------------------------------------------------------------------------
+// One wave per (sequence, new token, query head); f32 FMA.  Used for the
+// reference's small test shapes; not a performance path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+
+#include "nvllm_kernels.hpp"
+
+namespace nvllm {
+namespace kernels {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;  // one 16-byte load / MFMA operand
+
+constexpr int kD = 128;          // head_dim of the fast path
+constexpr int kBS = 16;          // block_size of the fast path
+constexpr int kRowBytes = kD * 2;
+constexpr int kTileBlocks = 2;   // 32 tokens per tile
+constexpr int kLdsPerWave = kTileBlocks * kBS * kRowBytes;  // 8 KiB
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    // round-to-nearest-even via the hardware convert (v_cvt_pk_bf16_f32)
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 r;
+    r[0] = static_cast<__bf16>(lo);
+    r[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+struct TileRegs {
+    u32x4 k[kTileBlocks][4];  // [block][k-step]   MFMA A fragments of K
+    u32x4 v[kTileBlocks][4];  // [block][row quad] coalesced rows of V
+};
+
+// NQT = number of 16-row query tiles (1: R <= 16, 2: R <= 32)
+template <int NQT, int HPB, bool NT>
+__global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
+    const __bf16 *__restrict__ q, const unsigned char *__restrict__ k_cache,
+    const unsigned char *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
+    const int32_t *__restrict__ context_lens, __bf16 *__restrict__ out,
+    float *__restrict__ ws_o, float *__restrict__ ws_ml, int T, int Hq, int Hkv,
+    int max_blocks_per_seq, int64_t num_cache_blocks, float scale_log2e, int num_splits,
+    int blocks_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[HPB * kLdsPerWave];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;   // lane group
+    const int c = lane & 15;   // query row within a q tile / token row / d within a d tile
+    const int split = blockIdx.x;
+    const int seq = blockIdx.y;
+    const int kvh = blockIdx.z * HPB + wave;
+    if (kvh >= Hkv) return;  // whole wave; no barriers are used anywhere
+
+    const int G = Hq / Hkv;
+    const int R = T * G;
+    const int ctx = context_lens[seq];
+    int nblk_seq = ctx > 0 ? (ctx + kBS - 1) / kBS : 0;
+    if (nblk_seq > max_blocks_per_seq) nblk_seq = max_blocks_per_seq;  // never read past the table row
+    const int blk_begin = split * blocks_per_split;
+    int blk_end = blk_begin + blocks_per_split;
+    if (blk_end > nblk_seq) blk_end = nblk_seq;
+    const int ntiles = blk_end > blk_begin ? (blk_end - blk_begin + kTileBlocks - 1) / kTileBlocks : 0;
+
+    unsigned char *lds = lds_all + wave * kLdsPerWave;
+    const int32_t *table = block_tables + (int64_t)seq * max_blocks_per_seq;
+
+    // ---- Q^T fragments (B operand): lane (g,c) holds Q[row c][32s+8g .. +7]
+    u32x4 qf[NQT][4];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int r = qt * 16 + c;
+        const bool valid = r < R;
+        const int t = valid ? r / G : 0;
+        const int hg = valid ? r - t * G : 0;
+        const __bf16 *qrow = q + (((int64_t)seq * T + t) * Hq + kvh * G + hg) * kD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 x = u32x4{0u, 0u, 0u, 0u};
+            if (valid) x = *reinterpret_cast<const u32x4 *>(qrow + 32 * s + 8 * g);
+            qf[qt][s] = x;
+        }
+    }
+    // new-token index of this lane's query rows (for the causal mask)
+    int t_of_row[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int r = qt * 16 + c;
+        t_of_row[qt] = r < R ? r / G : 0;
+    }
+
+    const int64_t block_bytes = (int64_t)kBS * Hkv * kRowBytes;
+    const unsigned row_stride = (unsigned)Hkv * kRowBytes;
+    const unsigned k_lane_off = (unsigned)c * row_stride + (unsigned)kvh * kRowBytes + 16u * g;
+    const unsigned v_lane_off = (unsigned)g * row_stride + (unsigned)kvh * kRowBytes + 16u * c;
+    // LDS addresses.  Row r of block b sits at b*4096 + r*256; its 16-byte chunk
+    // ch is stored at chunk position ch ^ (2*(r&7)) (conflict-free tr reads).
+    unsigned lds_wr[4];  // write address of V row (4i+g), chunk c
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * i + g;
+        lds_wr[i] = (unsigned)(r * kRowBytes + 16 * (c ^ (2 * (r & 7))));
+    }
+    // transposed read: lane c = 4*qq + p of group g addresses row 4g+qq,
+    // elements 16*dt + 4p .. +3  => chunk 2*dt + (p>>1), byte 8*(p&1) in chunk.
+    const int qq = c >> 2, p = c & 3;
+    const int tr_row = 4 * g + qq;
+    const unsigned tr_base = (unsigned)(tr_row * kRowBytes + 8 * (p & 1));
+    const int tr_sw = 2 * (tr_row & 7);
+    const int tr_ch0 = p >> 1;
+
+    auto clamp_id = [&](int id) -> int64_t {
+        int64_t x = id;
+        if (x < 0) x = 0;
+        if (x >= num_cache_blocks) x = num_cache_blocks - 1;
+        return x;
+    };
+    // physical ids of tile t (second id duplicated when the split ends on an odd block)
+    auto load_ids = [&](int t, int &p0, int &p1) {
+        const int b0 = blk_begin + kTileBlocks * t;
+        if (t < ntiles) {
+            p0 = table[b0];
+            p1 = (b0 + 1 < blk_end) ? table[b0 + 1] : p0;
+        } else {
+            p0 = 0;
+            p1 = 0;
+        }
+    };
+    auto load_tile = [&](TileRegs &tr, int p0, int p1) {
+        const int64_t pid[kTileBlocks] = {clamp_id(p0), clamp_id(p1)};
+#pragma unroll
+        for (int b = 0; b < kTileBlocks; ++b) {
+            const unsigned char *kb = k_cache + pid[b] * block_bytes + k_lane_off;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const u32x4 *ptr = reinterpret_cast<const u32x4 *>(kb + 64 * s);
+                tr.k[b][s] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kTileBlocks; ++b) {
+            const unsigned char *vb = v_cache + pid[b] * block_bytes + v_lane_off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 *ptr = reinterpret_cast<const u32x4 *>(vb + (size_t)(4 * i) * row_stride);
+                tr.v[b][i] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+            }
+        }
+    };
+
+    // ---- running state (exp2 domain)
+    float m_run[NQT], l_run[NQT];
+    f32x4 acc[NQT][8];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) acc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // first token that some query row cannot see (bottom-right mask); tiles
+    // that end at or before it need no masking at all
+    const int first_masked_tok = ctx - (T - 1);
+
+    auto compute_tile = [&](TileRegs &tr, int t) {
+        const int tok0 = (blk_begin + kTileBlocks * t) * kBS;
+        const bool tail = (tok0 + kTileBlocks * kBS > first_masked_tok) ||
+                          (blk_begin + kTileBlocks * t + 1 >= blk_end);
+        // ---- S^T = K Q^T
+        f32x4 s[NQT][kTileBlocks];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int b = 0; b < kTileBlocks; ++b) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, tr.k[b][ks]),
+                        __builtin_bit_cast(bf16x8, qf[qt][ks]), a, 0, 0, 0);
+                s[qt][b] = a;
+            }
+        // ---- stage V into LDS (zero rows past the context in the tail)
+        if (tail) {
+#pragma unroll
+            for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tok = tok0 + b * kBS + 4 * i + g;
+                    const bool live = (tok < ctx) && (blk_begin + kTileBlocks * t + b < blk_end);
+                    if (!live) tr.v[b][i] = u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<u32x4 *>(lds + b * (kBS * kRowBytes) + lds_wr[i]) = tr.v[b][i];
+
+        // ---- online softmax (scores scaled into the exp2 domain)
+        u32x4 pfrag[NQT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            float sv[8];
+#pragma unroll
+            for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sv[4 * b + j] = s[qt][b][j] * scale_log2e;
+            if (tail) {
+                const int limit = ctx - T + t_of_row[qt];  // last visible key position
+#pragma unroll
+                for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int tok = tok0 + b * kBS + 4 * g + j;
+                        const bool vis = (tok <= limit) && (blk_begin + kTileBlocks * t + b < blk_end);
+                        if (!vis) sv[4 * b + j] = -INFINITY;
+                    }
+            }
+            float mx = sv[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sv[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = fast_exp2(m_run[qt] - m_safe);
+            float pe[8], psum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pe[j] = fast_exp2(sv[j] - m_safe);
+                psum += pe[j];
+            }
+            l_run[qt] = l_run[qt] * alpha + psum;
+            m_run[qt] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) acc[qt][dt] *= alpha;
+            pfrag[qt] = u32x4{pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]),
+                              pack_bf16x2(pe[4], pe[5]), pack_bf16x2(pe[6], pe[7])};
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const unsigned off = tr_base + 16u * (unsigned)((2 * dt + tr_ch0) ^ tr_sw);
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4 *)(lds + off));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4 *)(lds + kBS * kRowBytes + off));
+            const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+                acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pfrag[qt]),
+                    acc[qt][dt], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: register double buffering, ids two tiles ahead
+    if (ntiles > 0) {
+        TileRegs ta, tb;
+        int a0, a1, n0, n1;
+        load_ids(0, a0, a1);
+        load_ids(1, n0, n1);
+        load_tile(ta, a0, a1);
+        for (int t = 0; t < ntiles; t += 2) {
+            int nn0, nn1;
+            load_ids(t + 2, nn0, nn1);
+            if (t + 1 < ntiles) load_tile(tb, n0, n1);
+            compute_tile(ta, t);
+            if (t + 1 >= ntiles) break;
+            load_ids(t + 3, n0, n1);
+            if (t + 2 < ntiles) load_tile(ta, nn0, nn1);
+            compute_tile(tb, t + 1);
+        }
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int r = qt * 16 + c;
+        if (r >= R) continue;
+        const int t = r / G, hg = r - t * G;
+        const int64_t orow = ((int64_t)seq * T + t) * Hq + kvh * G + hg;
+        if (num_splits == 1) {
+            const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+            __bf16 *op = out + orow * kD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                uint2 w;
+                w.x = pack_bf16x2(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv);
+                w.y = pack_bf16x2(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv);
+                *reinterpret_cast<uint2 *>(op + 16 * dt) = w;
+            }
+        } else {
+            const int64_t prow = orow * num_splits + split;
+            float *op = ws_o + prow * kD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+                *reinterpret_cast<f32x4 *>(op + 16 * dt) = acc[qt][dt];
+            if (g == 0) {
+                ws_ml[2 * prow] = m_run[qt];
+                ws_ml[2 * prow + 1] = l;
+            }
+        }
+    }
+}
+
+// K2b: combine split-K partials.  One wave per output row (seq, t, head);
+// lane owns d = 2*lane, 2*lane+1.
+__global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float *__restrict__ ws_o,
+                                                               const float *__restrict__ ws_ml,
+                                                               __bf16 *__restrict__ out,
+                                                               int64_t num_rows, int num_splits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= num_rows) return;
+    float m = -INFINITY;
+    for (int s = 0; s < num_splits; ++s) m = fmaxf(m, ws_ml[2 * (row * num_splits + s)]);
+    float L = 0.0f, o0 = 0.0f, o1 = 0.0f;
+    for (int s = 0; s < num_splits; ++s) {
+        const int64_t pr = row * num_splits + s;
+        const float ms = ws_ml[2 * pr], ls = ws_ml[2 * pr + 1];
+        const float w = (ms == -INFINITY) ? 0.0f : fast_exp2(ms - m);
+        L += ls * w;
+        const float2 o = *reinterpret_cast<const float2 *>(ws_o + pr * kD + 2 * lane);
+        o0 += o.x * w;
+        o1 += o.y * w;
+    }
+    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+    *reinterpret_cast<unsigned *>(out + row * kD + 2 * lane) = pack_bf16x2(o0 * inv, o1 * inv);
+}
+
+// ---------------------------------------------------------------------------
+// Generic path: one wave per (seq, t, head); any D <= 256, any block size.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float to_f32(T x);
+template <>
+__device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ float to_f32<__bf16>(__bf16 x) { return static_cast<float>(x); }
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ __bf16 from_f32<__bf16>(float x) { return static_cast<__bf16>(x); }
+
+template <typename ET>
+__global__ __launch_bounds__(64) void paged_attn_generic_kernel(
+    const ET *__restrict__ q, const ET *__restrict__ k_cache, const ET *__restrict__ v_cache,
+    const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
+    ET *__restrict__ out, int T, int Hq, int Hkv, int D, int block_size, int max_blocks_per_seq,
+    int64_t num_cache_blocks, float scale) {
+    __shared__ float q_s[256];
+    __shared__ float p_s[64];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x, t = blockIdx.y, seq = blockIdx.z;
+    const int kvh = h / (Hq / Hkv);
+    const int ctx = context_lens[seq];
+    ET *orow = out + (((int64_t)seq * T + t) * Hq + h) * D;
+    if (ctx <= 0) {
+        for (int d = lane; d < D; d += 64) orow[d] = from_f32<ET>(0.0f);
+        return;
+    }
+    const ET *qrow = q + (((int64_t)seq * T + t) * Hq + h) * D;
+    for (int d = lane; d < D; d += 64) q_s[d] = to_f32<ET>(qrow[d]);
+    __syncthreads();
+    const int32_t *table = block_tables + (int64_t)seq * max_blocks_per_seq;
+    const int limit = (T > 1) ? (ctx - T + t) : (ctx - 1);  // last visible key (paged.rs:357-381)
+    float m = -INFINITY, l = 0.0f;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};  // dims lane, lane+64, lane+128, lane+192
+    for (int base = 0; base <= limit; base += 64) {
+        const int tok = base + lane;
+        float s = -INFINITY;
+        if (tok <= limit) {
+            int64_t pb = table[tok / block_size];
+            if (pb < 0) pb = 0;
+            if (pb >= num_cache_blocks) pb = num_cache_blocks - 1;
+            const ET *krow = k_cache + ((pb * block_size + tok % block_size) * Hkv + kvh) * D;
+            float acc = 0.0f;
+            for (int d = 0; d < D; ++d) acc += q_s[d] * to_f32<ET>(krow[d]);
+            s = acc * scale;
+        }
+        float mx = s;
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = expf(m - m_new);
+        const float pj = (tok <= limit) ? expf(s - m_new) : 0.0f;
+        float ps = pj;
+        for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+        l = l * alpha + ps;
+        m = m_new;
+        __syncthreads();
+        p_s[lane] = pj;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        const int n = (limit - base + 1) < 64 ? (limit - base + 1) : 64;
+        for (int j = 0; j < n; ++j) {
+            const int tk = base + j;
+            int64_t pb = table[tk / block_size];
+            if (pb < 0) pb = 0;
+            if (pb >= num_cache_blocks) pb = num_cache_blocks - 1;
+            const ET *vrow = v_cache + ((pb * block_size + tk % block_size) * Hkv + kvh) * D;
+            const float pw = p_s[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) o[i] += pw * to_f32<ET>(vrow[d]);
+            }
+        }
+    }
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) orow[d] = from_f32<ET>(o[i] * inv);
+    }
+}
+
+int env_int(const char *name, int dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return std::atoi(s);
+}
+
+template <int NQT, int HPB>
+void launch_fast(const PagedAttnArgs &a, int splits, int bps, float *ws_o, float *ws_ml,
+                 bool nt, hipStream_t stream) {
+    const dim3 grid(splits, a.num_seqs, (a.num_kv_heads + HPB - 1) / HPB), block(64 * HPB);
+    const float scale_log2e = a.scale * 1.4426950408889634f;
+    auto q = static_cast<const __bf16 *>(a.q);
+    auto kc = static_cast<const unsigned char *>(a.k_cache);
+    auto vc = static_cast<const unsigned char *>(a.v_cache);
+    auto o = static_cast<__bf16 *>(a.out);
+    if (nt)
+        paged_attn_kernel<NQT, HPB, true><<<grid, block, 0, stream>>>(
+            q, kc, vc, a.block_tables, a.context_lens, o, ws_o, ws_ml, a.num_new_tokens,
+            a.num_heads, a.num_kv_heads, a.max_blocks_per_seq, a.num_cache_blocks, scale_log2e,
+            splits, bps);
+    else
+        paged_attn_kernel<NQT, HPB, false><<<grid, block, 0, stream>>>(
+            q, kc, vc, a.block_tables, a.context_lens, o, ws_o, ws_ml, a.num_new_tokens,
+            a.num_heads, a.num_kv_heads, a.max_blocks_per_seq, a.num_cache_blocks, scale_log2e,
+            splits, bps);
+}
+
+}  // namespace
+
+bool paged_attn_fast_path(DType dt, int T, int Hq, int Hkv, int D, int block_size) {
+    if (dt != DType::BF16 || D != kD || block_size != kBS) return false;
+    if (Hkv <= 0 || Hq % Hkv != 0 || T <= 0) return false;
+    return T * (Hq / Hkv) <= 32;
+}
+
+int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq) {
+    const int forced = env_int("NVLLM_PAGED_SPLITS", 0);
+    int max_splits = max_blocks_per_seq / 16;  // at least 16 blocks (256 tokens) per split
+    if (max_splits < 1) max_splits = 1;
+    if (max_splits > 64) max_splits = 64;
+    if (forced > 0) return forced < max_splits ? forced : max_splits;
+    // aim for >= 4096 (sequence, kv head, split) waves: 16 per CU on 256 CUs
+    const long waves = (long)num_seqs * num_kv_heads;
+    long splits = (4096 + waves - 1) / (waves > 0 ? waves : 1);
+    if (splits < 1) splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    return (int)splits;
+}
+
+size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
+                                  int max_blocks_per_seq) {
+    if (!paged_attn_fast_path(DType::BF16, T, Hq, Hkv, D, block_size)) return 0;
+    const int splits = paged_attn_num_splits(num_seqs, Hkv, max_blocks_per_seq);
+    if (splits <= 1) return 0;
+    const size_t rows = (size_t)num_seqs * T * Hq * splits;
+    return rows * (kD + 2) * sizeof(float);
+}
+
+hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {
+    if (a.num_seqs <= 0) return hipSuccess;
+    if (paged_attn_fast_path(dt, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
+                             a.block_size)) {
+        int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);
+        const size_t rows = (size_t)a.num_seqs * a.num_new_tokens * a.num_heads;
+        if (splits > 1 && a.workspace_bytes < rows * splits * (kD + 2) * sizeof(float)) splits = 1;
+        int bps = (a.max_blocks_per_seq + splits - 1) / splits;
+        bps = (bps + kTileBlocks - 1) / kTileBlocks * kTileBlocks;
+        if (bps < kTileBlocks) bps = kTileBlocks;
+        float *ws_o = static_cast<float *>(a.workspace);
+        float *ws_ml = ws_o ? ws_o + rows * splits * kD : nullptr;
+        const bool nt = env_int("NVLLM_PAGED_NT", 0) != 0;
+        const int R = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
+        int hpb = env_int("NVLLM_PAGED_HPB", 0);
+        if (hpb != 1 && hpb != 2 && hpb != 4 && hpb != 8) hpb = a.num_kv_heads >= 8 ? 8 : (a.num_kv_heads >= 4 ? 4 : (a.num_kv_heads >= 2 ? 2 : 1));
+        if (R <= 16) {
+            switch (hpb) {
+                case 8: launch_fast<1, 8>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                case 4: launch_fast<1, 4>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                case 2: launch_fast<1, 2>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                default: launch_fast<1, 1>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+            }
+        } else {
+            switch (hpb) {
+                case 8: launch_fast<2, 8>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                case 4: launch_fast<2, 4>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                case 2: launch_fast<2, 2>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+                default: launch_fast<2, 1>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
+            }
+        }
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+        if (splits > 1) {
+            const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+            paged_attn_merge_kernel<<<grid, block, 0, stream>>>(
+                ws_o, ws_ml, static_cast<__bf16 *>(a.out), (int64_t)rows, splits);
+            err = hipGetLastError();
+        }
+        return err;
+    }
+    // generic
+    const dim3 grid(a.num_heads, a.num_new_tokens, a.num_seqs), block(64);
+    if (dt == DType::BF16)
+        paged_attn_generic_kernel<__bf16><<<grid, block, 0, stream>>>(
+            static_cast<const __bf16 *>(a.q), static_cast<const __bf16 *>(a.k_cache),
+            static_cast<const __bf16 *>(a.v_cache), a.block_tables, a.context_lens,
+            static_cast<__bf16 *>(a.out), a.num_new_tokens, a.num_heads, a.num_kv_heads,
+            a.head_dim, a.block_size, a.max_blocks_per_seq, a.num_cache_blocks, a.scale);
+    else
+        paged_attn_generic_kernel<float><<<grid, block, 0, stream>>>(
+            static_cast<const float *>(a.q), static_cast<const float *>(a.k_cache),
+            static_cast<const float *>(a.v_cache), a.block_tables, a.context_lens,
+            static_cast<float *>(a.out), a.num_new_tokens, a.num_heads, a.num_kv_heads,
+            a.head_dim, a.block_size, a.max_blocks_per_seq, a.num_cache_blocks, a.scale);
+    return hipGetLastError();
+}
+
+}  // namespace kernels
+}  // namespace nvllm
