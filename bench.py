@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the attention hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|prefill|kvwrite]
+
+Headline (default, BASELINE.json `metric`): paged-decode attention GB/s on
+BASELINE config 3 -- 256 sequences x 2048-token contexts, 32 Q / 8 KV heads,
+head_dim 128, block_size 16, bf16, physical blocks a seeded random permutation
+of a 40,960-block pool.  A "step" is ONE launch of the paged-attention hot path
+over the whole batch for one layer; steps rotate over several disjoint layer
+caches so nothing is re-read out of L2 / Infinity Cache.  Inputs are resident
+in HBM before the timed region.
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the sequences
+are sharded: every rank owns its own 256 sequences, block pool and cache -- no
+data-path collective ("weak" scaling); value = bytes all ranks processed / the
+max-over-ranks time.
+
+One JSON line is printed by rank 0.  `roofline` is the dominant kernel's
+algorithmic bytes (or FLOPs) per launch / its average launch duration measured
+with HIP events on the launch stream; `cpu_baseline` is the CPU oracle
+(op-for-op restatement of the reference's Rust path, f32, OpenMP) timed on a
+bounded sample on this host.  The default run also measures the prefill
+flash-attention kernel (BASELINE config 2) and the KV write and reports them
+under "also".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md, spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec; not the 2:1-sparse figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="decode",
+                    choices=["decode", "shared", "long", "prefill", "kvwrite"])
+    ap.add_argument("--num-seqs", type=int, default=0)
+    ap.add_argument("--ctx", type=int, default=0)
+    ap.add_argument("--layers", type=int, default=0, help="disjoint layer caches rotated over")
+    ap.add_argument("--batch", type=int, default=1, help="prefill batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 and world != n:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (n, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return rank, local_rank, world
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_loop(fn, steps, warmup, world, dev):
+    """W warm-ups, then exactly K steps between barrier+synchronize pairs.
+    Returns (wall seconds max over ranks, mean per-launch ms from HIP events)."""
+    for i in range(warmup):
+        fn(i)
+    barrier(world)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        fn(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier(world)
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) / steps
+    return max_over_ranks(wall, world, dev), max_over_ranks(ev_ms, world, dev)
+
+
+# ------------------------------------------------------------------------------------------
+def build_decode_case(nv, dev, seed, num_seqs, ctx, T, Hq, Hkv, D, bs, layers, shared_prefix_tokens=0,
+                      pool_blocks=None):
+    """Block tables through the product BlockManager/BlockTable (allocate_with_prefix for the
+    shared prefix), physical ids a seeded permutation of the pool, caches filled with N(0,1)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    blocks_per_seq = -(-ctx // bs)
+    shared_blocks = shared_prefix_tokens // bs
+    need = shared_blocks + num_seqs * (blocks_per_seq - shared_blocks)
+    if pool_blocks is None:
+        pool_blocks = max(need + need // 4, need + 16)
+    perm = torch.randperm(pool_blocks, generator=g)
+    # the allocator hands out ascending ids (FIFO free list); the permutation maps them to
+    # scattered physical blocks so tables are non-contiguous as BASELINE.md asks
+    mgr = nv.BlockManager(pool_blocks, bs)
+    tables = np.zeros((num_seqs, blocks_per_seq), dtype=np.int32)
+    prefix_hashes = []
+    parent = None
+    for b in range(shared_blocks):
+        parent = nv.hash_token_block(np.arange(b * bs, (b + 1) * bs, dtype=np.uint32), parent)
+        prefix_hashes.append(parent)
+    for s in range(num_seqs):
+        ids = []
+        for b in range(shared_blocks):
+            bid, _ = mgr.allocate_with_prefix(prefix_hashes[b])
+            ids.append(bid)
+        ids.extend(mgr.allocate_many(blocks_per_seq - shared_blocks))
+        tables[s] = perm[torch.tensor(ids)].numpy()
+    if shared_blocks:
+        assert mgr.ref_count(0) == num_seqs
+    unique_blocks = need
+    block_tables = torch.from_numpy(tables).to(dev)
+    context_lens = torch.full((num_seqs,), ctx, dtype=torch.int32, device=dev)
+    caches = []
+    for _ in range(layers):
+        kc = torch.randn((pool_blocks, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
+        vc = torch.randn((pool_blocks, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
+        caches.append((kc, vc))
+    q = torch.randn((num_seqs, T, Hq, D), device=dev, dtype=torch.bfloat16)
+    return dict(q=q, caches=caches, block_tables=block_tables, context_lens=context_lens,
+                tables_np=tables, unique_blocks=unique_blocks, pool_blocks=pool_blocks)
+
+
+def cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget_s, bytes_per_seq):
+    """Time the CPU oracle (reference's per-sequence paged_attention, f32, OpenMP) on a bounded
+    sample of the same sequences; report it in the metric's unit (bf16-equivalent GB/s)."""
+    import oracle
+    kc, vc = case["caches"][0]
+    tables = case["tables_np"]
+    q = case["q"].float().cpu().numpy()
+    n_total = tables.shape[0]
+    done, t_used, outs = 0, 0.0, []
+    # one untimed call to warm caches / thread pool
+    sub = np.unique(tables[0])
+    remap = {int(b): i for i, b in enumerate(sub)}
+    while done < n_total and (done < 2 or t_used < budget_s):
+        ids = tables[done]
+        # gather this sequence's blocks to the host as f32 (untimed: the reference holds f32 caches)
+        sub = np.unique(ids)
+        remap = {int(b): i for i, b in enumerate(sub)}
+        idx = torch.from_numpy(sub.astype(np.int64)).to(kc.device)
+        kch = kc[idx].float().cpu().numpy()
+        vch = vc[idx].float().cpu().numpy()
+        local_ids = [remap[int(b)] for b in ids]
+        t0 = time.perf_counter()
+        o = oracle.paged_attention(q[done:done + 1], kch, vch, local_ids, bs, ctx, Hq, Hkv, D, scale)
+        t_used += time.perf_counter() - t0
+        outs.append(o)
+        done += 1
+    gbs = done * bytes_per_seq / t_used / 1e9
+    return dict(value=gbs, unit="GB/s", cores=oracle.num_threads(), kind="port",
+                sample="%d of %d sequences (ctx %d) through oracle.paged_attention, one call per "
+                       "sequence as the reference API works; %.1f s of CPU; bytes counted as the "
+                       "same bf16 KV bytes the GPU metric uses" % (done, n_total, ctx, t_used),
+                seconds=t_used), np.concatenate(outs, axis=0)
+
+
+def run_decode(args, nv, dev, rank, world, workload):
+    Hq, Hkv, D, bs = 32, 8, 128, 16
+    scale = 1.0 / math.sqrt(D)
+    if workload == "decode":      # BASELINE config 3
+        num_seqs, ctx, T, shared = args.num_seqs or 256, args.ctx or 2048, 1, 0
+        layers = args.layers or 4
+        pool = 40960 if (num_seqs == 256 and ctx == 2048) else None
+        name = "config3: paged decode, %d seqs x %d ctx, 32Q/8KV, hd128, block 16, T=1" % (num_seqs, ctx)
+    elif workload == "shared":    # BASELINE config 4
+        num_seqs, ctx, T, shared = args.num_seqs or 256, args.ctx or 2048, 4, (args.ctx or 2048) // 2
+        layers = args.layers or 4
+        pool = None
+        name = ("config4: shared-prefix decode + spec-verify, %d seqs, T=4, ctx %d = %d shared + %d private"
+                % (num_seqs, ctx, shared, ctx - shared))
+    else:                          # BASELINE config 5 (per-GPU shard of 1024/n sequences)
+        total = args.num_seqs or 1024
+        num_seqs, ctx, T, shared = max(total // max(args.gpus, 1), 1), args.ctx or 32768, 1, 0
+        layers = args.layers or 1
+        pool = None
+        name = ("config5: long-context paged decode, %d seqs/GPU x %d ctx (1024 total sharded %d-way)"
+                % (num_seqs, ctx, args.gpus))
+    case = build_decode_case(nv, dev, 3 + rank, num_seqs, ctx, T, Hq, Hkv, D, bs, layers, shared, pool)
+    token_bytes = 2 * Hkv * D * 2
+    logical_bytes = num_seqs * ctx * token_bytes
+    unique_bytes = case["unique_blocks"] * bs * token_bytes
+    aux_bytes = 2 * num_seqs * T * Hq * D * 2 + case["block_tables"].numel() * 4
+    need = nv.capi.lib().nvllm_paged_attn_workspace_bytes(num_seqs, T, Hq, Hkv, D, bs,
+                                                          case["block_tables"].shape[1])
+    ws = torch.empty(int(need), dtype=torch.uint8, device=dev) if need else None
+    outs = [None]
+
+    def step(i):
+        kc, vc = case["caches"][i % layers]
+        outs[0] = nv.paged_attention_batched(case["q"], kc, vc, case["block_tables"],
+                                             case["context_lens"], scale, workspace=ws)
+
+    wall, ev_ms = timed_loop(step, args.steps, args.warmup, world, dev)
+    algo_bytes = unique_bytes  # roofline numerator: bytes that must come from HBM
+    res = dict(
+        metric="paged_decode_attn_GBps", unit="GB/s",
+        value=world * algo_bytes * args.steps / wall / 1e9,
+        ms_per_step=wall / args.steps * 1e3,
+        config=dict(workload=name, num_seqs_per_gpu=num_seqs, context_len=ctx, new_tokens=T,
+                    num_q_heads=Hq, num_kv_heads=Hkv, head_dim=D, block_size=bs,
+                    layer_caches_rotated=layers, pool_blocks=case["pool_blocks"],
+                    parallelism="sequence-sharded x%d (no collective)" % world,
+                    algorithmic_bytes_per_step_per_gpu=algo_bytes,
+                    logical_bytes_per_step_per_gpu=logical_bytes, qo_table_bytes=aux_bytes),
+        roofline=dict(bound="hbm", achieved=algo_bytes / (ev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                      unit="GB/s", frac=algo_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      traffic=None, kernel="paged_attn_kernel",
+                      launch_ms=ev_ms, effective_logical_GBps=logical_bytes / (ev_ms * 1e-3) / 1e9),
+    )
+    if rank == 0 and not args.no_cpu_baseline:
+        budget = args.cpu_seconds if workload != "long" else args.cpu_seconds
+        cb, want = cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget,
+                                       ctx * token_bytes)
+        # the timed oracle outputs double as a parity check of the benchmarked launch
+        step(0)
+        torch.cuda.synchronize()
+        got = outs[0][: want.shape[0]].float().cpu().numpy()
+        err = np.abs(got - want)
+        cb["parity_max_abs"] = float(err.max())
+        cb["parity_mean_abs"] = float(err.mean())
+        res["cpu_baseline"] = cb
+    return res
+
+
+def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
+    """BASELINE config 2: B=1, S=4096, 16 Q / 8 KV heads, hd128, causal, bf16."""
+    B, S, Hq, Hkv, D = args.batch, args.ctx or 4096, 16, 8, 128
+    g = torch.Generator(device="cpu").manual_seed(2 + rank)
+    q = torch.randn((B, S, Hq, D), generator=g).to(dev, torch.bfloat16)
+    k = torch.randn((B, S, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    v = torch.randn((B, S, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    cfg = nv.FlashAttentionConfig.new(D, True)
+    outs = [None]
+
+    def step(i):
+        outs[0] = nv.flash_attention(q, k, v, cfg)
+
+    wall, ev_ms = timed_loop(step, steps, warmup, world, dev)
+    flops = 4.0 * B * Hq * S * S * D * 0.5   # causal: 68.72 GFLOP at B=1,S=4096
+    res = dict(
+        metric="prefill_flash_attn_TFLOPs", unit="TFLOP/s",
+        value=world * flops * steps / wall / 1e12, ms_per_step=wall / steps * 1e3,
+        config=dict(workload="config2: flash-attn prefill B=%d S=%d 16Q/8KV hd128 causal bf16" % (B, S),
+                    algorithmic_flops_per_step_per_gpu=flops, parallelism="replicas x%d" % world),
+        roofline=dict(bound="mfma", achieved=flops / (ev_ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
+                      unit="TFLOP/s", frac=flops / (ev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                      traffic=None, kernel="flash_attn", launch_ms=ev_ms),
+    )
+    if rank == 0 and cpu and not args.no_cpu_baseline:
+        import oracle
+        # bounded sample: the first `hs` query heads (causal work per head is identical)
+        hs = 2
+        qs = q[:1, :, :hs].float().cpu().numpy()
+        ks = k[:1, :, :1].float().cpu().numpy()
+        vs = v[:1, :, :1].float().cpu().numpy()
+        t0 = time.perf_counter()
+        want = oracle.flash_attention_cpu(qs, ks, vs, True)
+        dt = time.perf_counter() - t0
+        got = outs[0][:1, :, :hs].float().cpu().numpy()
+        err = np.abs(got - want)
+        res["cpu_baseline"] = dict(
+            value=4.0 * hs * S * S * D * 0.5 / dt / 1e12, unit="TFLOP/s", cores=oracle.num_threads(),
+            kind="port", seconds=dt,
+            sample="%d of %d query heads of batch 0 through oracle.flash_attention_cpu (64x64 tiles, "
+                   "f32); causal FLOPs counted like the GPU metric" % (hs, Hq),
+            parity_max_abs=float(err.max()), parity_mean_abs=float(err.mean()))
+    return res
+
+
+def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
+    Hkv, D, bs, nb = 8, 128, 16, 40960
+    g = torch.Generator(device="cpu").manual_seed(6 + rank)
+    key = torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    val = torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    kc = torch.zeros((nb, bs, Hkv, D), dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    slots = torch.randperm(nb * bs, generator=g)[:num_tokens].to(dev)
+
+    def step(i):
+        nv.reshape_and_cache(key, val, kc, vc, slots)
+
+    wall, ev_ms = timed_loop(step, steps, warmup, world, dev)
+    bytes_moved = num_tokens * (2 * Hkv * D * 2) * 2 + num_tokens * 8   # read + written + slots
+    return dict(metric="kv_write_GBps", unit="GB/s", value=world * bytes_moved * steps / wall / 1e9,
+                ms_per_step=wall / steps * 1e3,
+                config=dict(workload="reshape_and_cache, %d tokens, 8 KV heads, hd128, bf16" % num_tokens,
+                            algorithmic_bytes_per_step_per_gpu=bytes_moved),
+                roofline=dict(bound="hbm", achieved=bytes_moved / (ev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                              unit="GB/s", frac=bytes_moved / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              traffic=None, kernel="reshape_and_cache_kernel", launch_ms=ev_ms))
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    rank, local_rank, world = dist_setup(args.gpus)
+    dev = torch.device("cuda", local_rank)
+    import nano_vllm_rs_amd as nv
+    nv.capi.lib()
+    if args.workload in ("decode", "shared", "long"):
+        res = run_decode(args, nv, dev, rank, world, args.workload)
+    elif args.workload == "prefill":
+        res = run_prefill(args, nv, dev, rank, world, args.steps, args.warmup)
+    else:
+        res = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, args.num_seqs or 4096)
+    also = {}
+    if args.workload == "decode" and not args.no_also and world == 1:
+        torch.cuda.empty_cache()
+        p = run_prefill(args, nv, dev, rank, world, max(args.steps // 10, 5), max(args.warmup // 10, 2))
+        also["prefill"] = {k: p[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline", "config")
+                           if k in p}
+        if "cpu_baseline" in p:
+            also["prefill"]["cpu_baseline"] = p["cpu_baseline"]
+        for n in (256, 4096):
+            w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, n)
+            also["kv_write_%d" % n] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
+                                           frac=w["roofline"]["frac"])
+    props = torch.cuda.get_device_properties(dev)
+    line = dict(
+        metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=world, steps=args.steps,
+        warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="bf16", data="synthetic", config=res["config"], roofline=res["roofline"],
+        cpu_baseline=res.get("cpu_baseline"),
+        device=dict(name=props.name, cus=props.multi_processor_count,
+                    hbm_gib=round(props.total_memory / 2**30, 1),
+                    peaks=dict(hbm_GBps=HBM_PEAK_GBS, mfma_bf16_TFLOPs=MFMA_BF16_PEAK_TFLOPS)),
+    )
+    if also:
+        line["also"] = also
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,8 +129,8 @@ def test_batched_reshape_and_cache_bf16(dev, num_tokens):
         slots_with_skip[3] = -1                      # skip marker
     key, value = bf16_randn(rng, (num_tokens, Hkv, D)), bf16_randn(rng, (num_tokens, Hkv, D))
     guard = 2    # guard blocks either side, filled with a sentinel that must survive
-    kc = torch.full((nb + 2 * guard, bs, Hkv, D), 777.0, dtype=torch.bfloat16, device=dev)
-    vc = torch.full_like(kc, 777.0)
+    kc = torch.full((nb + 2 * guard, bs, Hkv, D), 768.0, dtype=torch.bfloat16, device=dev)
+    vc = torch.full_like(kc, 768.0)
     kcv, vcv = kc[guard:guard + nb], vc[guard:guard + nb]
     kcv.zero_(); vcv.zero_()
     nv.reshape_and_cache(_to_dev(key, dev, torch.bfloat16), _to_dev(value, dev, torch.bfloat16),
@@ -143,7 +143,7 @@ def test_batched_reshape_and_cache_bf16(dev, num_tokens):
     assert np.array_equal(kcv.float().cpu().numpy(), want_k)
     assert np.array_equal(vcv.float().cpu().numpy(), want_v)
     for g in (kc[:guard], kc[guard + nb:], vc[:guard], vc[guard + nb:]):
-        assert (g.float() == 777.0).all()
+        assert bool((g.float() == 768.0).all())
 
 
 def test_round_trip_gather_recovers_tokens(dev):
