@@ -162,7 +162,7 @@ def cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget_s, bytes_per
     # one untimed call to warm caches / thread pool
     sub = np.unique(tables[0])
     remap = {int(b): i for i, b in enumerate(sub)}
-    while done < n_total and (done < 2 or t_used < budget_s):
+    while done < n_total and (done < 2 or t_used < budget_s):  # bounded by the budget
         ids = tables[done]
         # gather this sequence's blocks to the host as f32 (untimed: the reference holds f32 caches)
         sub = np.unique(ids)
@@ -278,21 +278,27 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
     )
     if rank == 0 and cpu and not args.no_cpu_baseline:
         import oracle
-        # bounded sample: the first `hs` query heads (causal work per head is identical)
-        hs = 2
-        qs = q[:1, :, :hs].float().cpu().numpy()
-        ks = k[:1, :, :1].float().cpu().numpy()
-        vs = v[:1, :, :1].float().cpu().numpy()
-        t0 = time.perf_counter()
-        want = oracle.flash_attention_cpu(qs, ks, vs, True)
-        dt = time.perf_counter() - t0
-        got = outs[0][:1, :, :hs].float().cpu().numpy()
+        # sample: every head of batch element 0 (the whole workload at B=1), repeated to ~budget
+        hs = Hq
+        qs = q[:1].float().cpu().numpy()
+        ks = k[:1].float().cpu().numpy()
+        vs = v[:1].float().cpu().numpy()
+        want = oracle.flash_attention_cpu(qs, ks, vs, True)   # untimed warm-up (thread pool, pages)
+        reps, dt = 0, 0.0
+        while reps < 2 or (dt < args.cpu_seconds and reps < 50):
+            t0 = time.perf_counter()
+            want = oracle.flash_attention_cpu(qs, ks, vs, True)
+            dt += time.perf_counter() - t0
+            reps += 1
+        dt /= reps
+        got = outs[0][:1].float().cpu().numpy()
         err = np.abs(got - want)
         res["cpu_baseline"] = dict(
             value=4.0 * hs * S * S * D * 0.5 / dt / 1e12, unit="TFLOP/s", cores=oracle.num_threads(),
             kind="port", seconds=dt,
-            sample="%d of %d query heads of batch 0 through oracle.flash_attention_cpu (64x64 tiles, "
-                   "f32); causal FLOPs counted like the GPU metric" % (hs, Hq),
+            sample="all %d query heads of batch element 0 through oracle.flash_attention_cpu (64x64 "
+                   "tiles, f32), mean of %d repetitions; causal FLOPs counted like the GPU metric"
+                   % (hs, reps),
             parity_max_abs=float(err.max()), parity_mean_abs=float(err.mean()))
     return res
 
