@@ -9,6 +9,7 @@ runs in libnvllm_attn.so (hand-written gfx950 HIP + C++ host code); nothing in
 this package falls back to PyTorch or to the CPU oracle.
 """
 from . import capi  # noqa: F401
+from . import sharding  # noqa: F401
 from .core import (  # noqa: F401
     DEFAULT_BLOCK_SIZE, BlockTable, BlockManager, KVCacheConfig, LayerKVCache, KVCache,
     compute_num_blocks, hash_token_block, NvllmError, ConfigError, OutOfBlocksError,

@@ -1,0 +1,87 @@
+"""Multi-GPU partitioning of the paged-attention path (no counterpart in the
+reference, which is single-device).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  Two modes:
+
+  * sequence-sharded (primary): rank r owns a contiguous range of sequences together with their
+    block pool, block tables and cache slab.  Sequences are independent units of
+    `paged_attention` (reference src/attention/paged.rs:117-192 touches one table and its
+    blocks), so the attention path needs NO collective; `gather_sequences` exists only for
+    callers that want the outputs replicated.
+  * kv-head-sharded: rank r holds KV heads [r*Hkv/n, (r+1)*Hkv/n) of every block (cache
+    [num_blocks, bs, Hkv/n, D]) and computes the matching Hq/n query heads of ALL sequences;
+    `all_gather_heads` then assembles [num_seqs, T, Hq*D] with ONE all-gather per layer.  The
+    per-rank message is num_seqs*T*(Hq/n)*D*2 bytes (256 KiB at config 3, n = 8): on the 7-link
+    xGMI mesh that is latency-bound, so it is a single collective, never a ring of small ones.
+"""
+import torch
+import torch.distributed as dist
+
+
+def sequence_range(num_seqs, world, rank):
+    """Contiguous, balanced [begin, end) of the sequences rank `rank` owns."""
+    base, rem = divmod(num_seqs, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def kv_head_range(num_kv_heads, world, rank):
+    """KV heads [begin, end) of rank `rank`; world must divide num_kv_heads."""
+    if num_kv_heads % world != 0:
+        raise ValueError("kv-head sharding needs world (%d) to divide num_kv_heads (%d)"
+                         % (world, num_kv_heads))
+    per = num_kv_heads // world
+    return rank * per, (rank + 1) * per
+
+
+def q_head_range(num_heads, num_kv_heads, world, rank):
+    """Query heads that read this rank's KV heads (GQA: q head h -> kv head h // (Hq/Hkv))."""
+    g = num_heads // num_kv_heads
+    b, e = kv_head_range(num_kv_heads, world, rank)
+    return b * g, e * g
+
+
+def shard_query_heads(query, num_kv_heads, world, rank):
+    """[N, T, Hq, D] -> this rank's [N, T, Hq/n, D] (contiguous copy)."""
+    b, e = q_head_range(query.shape[2], num_kv_heads, world, rank)
+    return query[:, :, b:e, :].contiguous()
+
+
+def shard_cache_heads(cache, world, rank):
+    """[num_blocks, bs, Hkv, D] -> this rank's [num_blocks, bs, Hkv/n, D] (contiguous copy)."""
+    b, e = kv_head_range(cache.shape[2], world, rank)
+    return cache[:, :, b:e, :].contiguous()
+
+
+def all_gather_heads(out_local, head_dim, group=None):
+    """out_local [N, T, (Hq/n)*D] on every rank -> [N, T, Hq*D] on every rank.
+    One all_gather_into_tensor (RCCL ncclAllGather) + a local permute of the small result."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return out_local
+    N, T, HD = out_local.shape
+    # output is the rank-major concatenation along dim 0 (the form every backend accepts)
+    gathered = torch.empty((world * N, T, HD), dtype=out_local.dtype, device=out_local.device)
+    dist.all_gather_into_tensor(gathered, out_local.contiguous(), group=group)
+    return gathered.view(world, N, T, HD).permute(1, 2, 0, 3).reshape(N, T, world * HD)
+
+
+def gather_sequences(out_local, num_seqs, group=None):
+    """Optional: replicate sequence-sharded outputs.  out_local [n_local, T, Hq*D] ->
+    [num_seqs, T, Hq*D] (ranks may own different counts)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return out_local
+    rank = dist.get_rank(group)
+    sizes = [sequence_range(num_seqs, world, r) for r in range(world)]
+    maxn = max(e - b for b, e in sizes)
+    pad = torch.zeros((maxn,) + tuple(out_local.shape[1:]), dtype=out_local.dtype,
+                      device=out_local.device)
+    b, e = sizes[rank]
+    pad[: e - b] = out_local
+    gathered = torch.empty((world * maxn,) + tuple(pad.shape[1:]), dtype=pad.dtype,
+                           device=pad.device)
+    dist.all_gather_into_tensor(gathered, pad, group=group)
+    gathered = gathered.view((world, maxn) + tuple(pad.shape[1:]))
+    return torch.cat([gathered[r, : sizes[r][1] - sizes[r][0]] for r in range(world)], dim=0)
