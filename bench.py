@@ -326,6 +326,18 @@ def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
                               traffic=None, kernel="reshape_and_cache_kernel", launch_ms=ev_ms))
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled
+    per the gfx950 correction).  Counters cannot be read inside this process; None if the
+    workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)[key]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -336,6 +348,8 @@ def main():
     nv.capi.lib()
     if args.workload in ("decode", "shared", "long"):
         res = run_decode(args, nv, dev, rank, world, args.workload)
+        if args.workload == "decode" and not args.num_seqs and not args.ctx:
+            res["roofline"]["traffic"] = pmc_traffic("config3_decode")
     elif args.workload == "prefill":
         res = run_prefill(args, nv, dev, rank, world, args.steps, args.warmup)
     else:
