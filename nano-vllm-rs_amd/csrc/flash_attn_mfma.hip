@@ -58,6 +58,7 @@ constexpr int kWaves = 4;
 constexpr int kQRows = 32 * kWaves;   // query rows per workgroup
 constexpr int kKV = 64;               // keys per tile
 constexpr int kTileBytes = kKV * kRowBytes;  // 16 KiB
+constexpr float kDeferLog2 = 6.0f;           // rescale only when a row max grows by > 2^6 (T13)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -132,14 +133,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
         const int kv0 = t * kKV;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = kv0 + st_row0 + 16 * i;
-            u32x4 kx = {0u, 0u, 0u, 0u}, vx = {0u, 0u, 0u, 0u};
-            if (r < Skv) {
-                kx = *reinterpret_cast<const u32x4 *>(k_base + (int64_t)r * kv_row_stride);
-                vx = *reinterpret_cast<const u32x4 *>(v_base + (int64_t)r * kv_row_stride);
-            }
-            kst[i] = kx;
-            vst[i] = vx;
+            // rows past the end are clamped to the last row: always a valid, finite load (no
+            // per-load branch); those keys are masked out of S, so their P is exactly 0
+            int r = kv0 + st_row0 + 16 * i;
+            r = r < Skv ? r : Skv - 1;
+            kst[i] = *reinterpret_cast<const u32x4 *>(k_base + (int64_t)r * kv_row_stride);
+            vst[i] = *reinterpret_cast<const u32x4 *>(v_base + (int64_t)r * kv_row_stride);
         }
     };
     auto stage_write = [&](int buf) {
@@ -196,26 +195,38 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                         0, 0);
                 }
             }
-            // ---- mask (diagonal or ragged tile only) and scale into the exp2 domain
+            // ---- mask: one wave-uniform branch, diagonal or ragged tiles only
             const bool need_mask = (kv0 + kKV > Skv) || (CAUSAL && (kv0 + kKV - 1 > qw0));
-            float mx = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool vis = (key < Skv) && (!CAUSAL || key <= qrow);
+                        s[u][r] = vis ? s[u][r] : -INFINITY;
+                    }
+            }
+            // ---- online softmax on raw scores; p = exp2(s*c - m*c), c = scale*log2(e)
+            float mx = s[0][0];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = s[u][r] * scale_log2e;
-                    if (need_mask) {
-                        const int key = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool vis = (key < Skv) && (!CAUSAL || key <= qrow);
-                        x = vis ? x : -INFINITY;
-                    }
-                    s[u][r] = x;
-                    mx = fmaxf(mx, x);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float alpha = fast_exp2(m_run - m_safe);
+            // deferred rescale: keep the old reference max while the row max grew by less than
+            // kDeferLog2 (in the exp2 domain), so P stays <= 2^kDeferLog2; otherwise rescale
+            // O and l once for the whole wave (wave-uniform branch)
+            if (__any((mx - m_run) * scale_log2e > kDeferLog2)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+                const float alpha = fast_exp2((m_run - m_safe) * scale_log2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[dt] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = ((m_run == -INFINITY) ? 0.0f : m_run) * scale_log2e;
             float psum = 0.0f;
             u32x4 pb[4];  // P^T B fragments, k-step sp = 2u + sh
 #pragma unroll
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                 float pe[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pe[r] = fast_exp2(s[u][r] - m_safe);
+                    pe[r] = fast_exp2(__builtin_fmaf(s[u][r], scale_log2e, -mc));
                     psum += pe[r];
                 }
 #pragma unroll
@@ -233,10 +244,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                                            pack_bf16x2(pe[8 * sh + 4], pe[8 * sh + 5]),
                                            pack_bf16x2(pe[8 * sh + 6], pe[8 * sh + 7])};
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[dt] *= alpha;
+            l_run += psum;
             // ---- O^T += V^T P^T
             const unsigned char *vt = v_lds + buf * kTileBytes + v_rd_base;
 #pragma unroll
@@ -275,7 +283,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                 *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
             }
         if (lse && h == 0)
-            lse[((int64_t)b * Hq + hq) * Sq + qrow] = m_run * 0.6931471805599453f + logf(l);
+            lse[((int64_t)b * Hq + hq) * Sq + qrow] =
+                m_run * scale_log2e * 0.6931471805599453f + logf(l);
     }
 }
 
