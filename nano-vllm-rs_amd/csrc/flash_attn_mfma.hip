@@ -91,7 +91,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
     const int kvh = bid % Hkv;
     bid /= Hkv;
     const int hg = bid % G;
-    const int qt = num_q_tiles - 1 - bid / G;
+    // Launch order of the query tiles: the heavy half in descending order, then the light half
+    // in ASCENDING order, so that (under the observed round-robin placement, speed only) the
+    // two workgroups that share a CU hold complementary amounts of causal work.
+    int qt = bid / G;
+    if (CAUSAL) {
+        const int half = (num_q_tiles + 1) / 2;
+        qt = qt < half ? num_q_tiles - 1 - qt : qt - half;
+    }
     const int hq = kvh * G + hg;
     const int b = blockIdx.y;
 
@@ -128,8 +135,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
         k_wr[i] = (unsigned)(r * kRowBytes + 16 * (st_ch ^ (r & 15)));
         v_wr[i] = (unsigned)(r * kRowBytes + 16 * (st_ch ^ (4 * (r & 3))));
     }
-    u32x4 kst[4], vst[4];
-    auto stage_load = [&](int t) {
+    // One staging register set, used twice per tile: K(t+1) is fetched at the top of tile t and
+    // written to LDS right after the QK^T phase; V(t+1) is fetched then and written at the end.
+    u32x4 st[4];
+    auto stage_load = [&](const __bf16 *base, int t) {
         const int kv0 = t * kKV;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,16 +146,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
             // per-load branch); those keys are masked out of S, so their P is exactly 0
             int r = kv0 + st_row0 + 16 * i;
             r = r < Skv ? r : Skv - 1;
-            kst[i] = *reinterpret_cast<const u32x4 *>(k_base + (int64_t)r * kv_row_stride);
-            vst[i] = *reinterpret_cast<const u32x4 *>(v_base + (int64_t)r * kv_row_stride);
+            st[i] = *reinterpret_cast<const u32x4 *>(base + (int64_t)r * kv_row_stride);
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](unsigned char *tile, const unsigned (&wr)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4 *>(k_lds + buf * kTileBytes + k_wr[i]) = kst[i];
-            *reinterpret_cast<u32x4 *>(v_lds + buf * kTileBytes + v_wr[i]) = vst[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4 *>(tile + wr[i]) = st[i];
     };
 
     // ---- LDS read addresses
@@ -168,19 +173,22 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.0f;
 
-    stage_load(0);
-    stage_write(0);
+    stage_load(k_base, 0);
+    stage_write(k_lds, k_wr);
+    stage_load(v_base, 0);
+    stage_write(v_lds, v_wr);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int kv0 = t * kKV;
-        if (t + 1 < ntiles) stage_load(t + 1);
+        const bool more = t + 1 < ntiles;
+        if (more) stage_load(k_base, t + 1);
 
         const bool wave_active = !CAUSAL || (kv0 <= qw0 + 31);
+        f32x16 s[2];
         if (wave_active) {
             // ---- S^T = K Q^T : two 32-key sub-tiles
-            f32x16 s[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -195,6 +203,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                         0, 0);
                 }
             }
+        }
+        if (more) {
+            stage_write(k_lds + (buf ^ 1) * kTileBytes, k_wr);
+            stage_load(v_base, t + 1);
+        }
+        if (wave_active) {
             // ---- mask: one wave-uniform branch, diagonal or ragged tiles only
             const bool need_mask = (kv0 + kKV > Skv) || (CAUSAL && (kv0 + kKV - 1 > qw0));
             if (need_mask) {
@@ -245,18 +259,27 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                                            pack_bf16x2(pe[8 * sh + 6], pe[8 * sh + 7])};
             }
             l_run += psum;
-            // ---- O^T += V^T P^T
+            // ---- O^T += V^T P^T : V fragments of d-tile dt+1 are read while dt is multiplied
             const unsigned char *vt = v_lds + buf * kTileBytes + v_rd_base;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            s16x4 vf[2][8];
+            auto load_vf = [&](s16x4 (&f)[8], int dt) {
                 const unsigned choff = 16u * (unsigned)((4 * dt + v_ch_lo) ^ v_sw);
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp) {
-                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                     const unsigned char *p0 = vt + sp * 16 * kRowBytes + choff;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
-                    const s16x4 v1 =
+                    f[2 * sp] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
+                    f[2 * sp + 1] =
                         __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kRowBytes));
+                }
+            };
+            load_vf(vf[0], 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                if (dt + 1 < 4) load_vf(vf[(dt + 1) & 1], dt + 1);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    const s16x4 v0 = vf[dt & 1][2 * sp], v1 = vf[dt & 1][2 * sp + 1];
                     const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pb[sp]), acc[dt],
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void flash_attn_mfma_kernel(
                 }
             }
         }
-        if (t + 1 < ntiles) stage_write(buf ^ 1);
+        if (more) stage_write(v_lds + (buf ^ 1) * kTileBytes, v_wr);
         __syncthreads();
     }
 
