@@ -158,6 +158,43 @@ int main(int argc, char **argv) {
                    (worst / D) % Hq, worst % D, (mx < 2e-2 && sum / nq < 1e-3) ? "OK" : "FAIL");
         }
     }
+    // stamped diagnostic variants (name starts with "stamp", built with -DNVLLM_K1_STAMPS) write
+    // per-wave segment cycle sums through the lse pointer: 8 x u64 per wave
+    for (int vi = 0; vi < nv; ++vi) {
+        const Variant &v = kVariants[vi];
+        if (strncmp(v.name, "stamp", 5) != 0 || !v.supported(a)) continue;
+        const size_t nwaves = (size_t)B * ((S + 127) / 128) * Hq * 8;  // upper bound (<= 8 waves/WG)
+        unsigned long long *dd;
+        CK(hipMalloc(&dd, nwaves * 128));
+        CK(hipMemset(dd, 0, nwaves * 128));
+        FlashAttnArgs sa = a;
+        sa.lse = reinterpret_cast<float *>(dd);
+        for (int i = 0; i < 3; ++i) CK(v.launch(sa, 0));
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hd(nwaves * 16);
+        CK(hipMemcpy(hd.data(), dd, nwaves * 128, hipMemcpyDeviceToHost));
+        // slots 0..11 = cycle sums of segments, 12..14 = counters, 15 = steps
+        double sum[16] = {0}; size_t n = 0; double mx_total = 0; size_t mx_i = 0;
+        for (size_t w = 0; w < nwaves; ++w) {
+            if (hd[w * 16 + 15] == 0) continue;
+            double tot = 0;
+            for (int i = 0; i < 12; ++i) tot += (double)hd[w * 16 + i];
+            if (tot > mx_total) { mx_total = tot; mx_i = w; }
+            for (int i = 0; i < 16; ++i) sum[i] += (double)hd[w * 16 + i];
+            ++n;
+        }
+        printf("%-14s stamps over %zu waves: steps/wave %.1f, counters c12=%.1f c13=%.1f c14=%.1f per wave\n", v.name, n,
+               sum[15] / n, sum[12] / n, sum[13] / n, sum[14] / n);
+        printf("%-14s   cycles per wave: ", v.name);
+        double tot = 0;
+        for (int i = 0; i < 12; ++i) { printf("s%d=%.0f ", i, sum[i] / n); tot += sum[i]; }
+        printf("total=%.0f\n", tot / n);
+        printf("%-14s   longest wave %zu (steps %llu, c12=%llu c13=%llu c14=%llu): ", v.name, mx_i, hd[mx_i * 16 + 15],
+               hd[mx_i * 16 + 12], hd[mx_i * 16 + 13], hd[mx_i * 16 + 14]);
+        for (int i = 0; i < 12; ++i) printf("s%d=%.0f ", i, (double)hd[mx_i * 16 + i]);
+        printf("total=%.0f cycles\n", mx_total);
+        hipFree(dd);
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < rounds + 1; ++r)

@@ -39,8 +39,6 @@
 
 #include <cmath>
 #include <cstdint>
-#include <type_traits>
-#include <utility>
 
 #include "nvllm_kernels.hpp"
 
@@ -68,22 +66,6 @@ constexpr int kKBase = kVRing * kVTile;
 constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 83,968 B
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
 
-// Diagnostic build only (scripts/k1_lab, -DNVLLM_K1_STAMPS): per-wave cycle sums of the loop's
-// segments, written through the lse pointer.  In the product build no stamp executes.
-#ifdef NVLLM_K1_STAMPS
-#define K1_STAMP(i)                                                                        \
-    do {                                                                                   \
-        unsigned long long t_;                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        seg_sum[i] += t_ - t_prev;                                                         \
-        t_prev = t_;                                                                       \
-    } while (0)
-#else
-#define K1_STAMP(i)
-#endif
-
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
@@ -94,16 +76,17 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-// max over the two lane halves (lane ^ 32): v_permlane32_swap exchanges the upper half of its
-// first operand with the lower half of its second, so with x in both, every lane ends up with
-// its own value in one register and the other half's in the other.  Inline asm: hipcc (ROCm 7.2)
-// folds the builtin's two results into one.  s_nop 1 = the VALU-write -> permlane wait states.
+// value of the other lane half (lane ^ 32) combined with this lane's
 __device__ __forceinline__ float half_max(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x),
+                                                    __builtin_bit_cast(unsigned, x), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
-__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32); }
+__device__ __forceinline__ float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x),
+                                                    __builtin_bit_cast(unsigned, x), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
 
 // One score register set: raw S^T of a 64-key tile for one 32-row block, the P^T fragments made
 // from it and the softmax constants of that item.
@@ -118,67 +101,28 @@ struct Item {
     bool need;      // wave-uniform: alpha != 1
 };
 
-// Per-block softmax state.  The O^T accumulators and the Q^T fragments of both blocks live in the
-// accumulator half of the register file under LITERAL names, out of the compiler's sight:
-//   O^T of block b, d-tile dt : a[64b + 16dt : 64b + 16dt + 15]
-//   Q^T of block b, k-step ks : a[128 + 32b + 4ks : 128 + 32b + 4ks + 3]
-// so that the vector ALU half (256 registers) is left to the softmax and the staging.  The
-// compiler never spills (checked at build time: zero spills, no v_accvgpr outside the asm
-// statements), so nothing else ever lands in a[0:191].
+// Per-block state.  acc and q are only ever touched by the MFMA statements below, which pin them
+// to the accumulator half of the register file ("a" constraints); the vector ALU works in the
+// other half.
 struct Block {
+    f32x16 acc[4];  // O^T accumulators (AGPR)
+    u32x4 q[8];     // Q^T B fragments (AGPR)
     float m, l;
     int qrow;  // this lane's query row
 };
-#define K1_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
-
-template <int I> using ic = std::integral_constant<int, I>;
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-    (f(ic<Is>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
-}
 
 // The MFMAs are inline asm so that the operand register files can be chosen.  hipcc neither
 // schedules around them nor pads their hazards (cdna_hip_programming.md 5.7): every VALU read of
 // an MFMA result below sits at least 12 wait states after the MFMA, by construction in the
 // pipelined bodies and by mfma_fence() elsewhere.
-template <int QR>
-__device__ __forceinline__ void mfma_qk_first(f32x16 &s, const u32x4 &kf) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
-                 : "=&v"(s) : "v"(kf), "i"(QR), "i"(QR + 3) : K1_AGPRS);
+__device__ __forceinline__ void mfma_qk_first(f32x16 &s, const u32x4 &kf, const u32x4 &qf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(qf));
 }
-template <int QR>
-__device__ __forceinline__ void mfma_qk(f32x16 &s, const u32x4 &kf) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
-                 : "+v"(s) : "v"(kf), "i"(QR), "i"(QR + 3) : K1_AGPRS);
+__device__ __forceinline__ void mfma_qk(f32x16 &s, const u32x4 &kf, const u32x4 &qf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(qf));
 }
-template <int AR>
-__device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &p) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
-                 : : "v"(vf), "v"(p), "i"(AR), "i"(AR + 15) : K1_AGPRS);
-}
-template <int R> __device__ __forceinline__ void agpr_write(unsigned x) {
-    asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(x), "i"(R));
-}
-template <int R> __device__ __forceinline__ float agpr_read() {
-    float x;
-    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(R));
-    return x;
-}
-template <int R> __device__ __forceinline__ void agpr_scale(float f) {
-    float t;
-    asm volatile("v_accvgpr_read_b32 %0, a%c2\n\ts_nop 1\n\tv_mul_f32 %0, %0, %1\n\ts_nop 1\n\t"
-                 "v_accvgpr_write_b32 a%c2, %0"
-                 : "=&v"(t) : "v"(f), "i"(R));
-}
-// Pins a value's computation at this point of the instruction stream: volatile asm statements
-// keep their order, so the vector-ALU work stays in the MFMA gap it was dealt to (without it
-// hipcc sinks the exponentials to their first use, past a whole slot of MFMAs).
-__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(float &x, float &y, u32x4 &z) {
-    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+__device__ __forceinline__ void mfma_pv(f32x16 &acc, const u32x4 &vf, const u32x4 &p) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(vf), "v"(p));
 }
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
@@ -236,69 +180,52 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     Block A, B;
     A.qrow = rowA0 + c;
     B.qrow = rowB0 + c;
-    // reserves a[0:191] in the kernel descriptor; every later statement names them literally
-    asm volatile("" ::: K1_AGPRS);
-    constexpr ic<0> kA{};
-    constexpr ic<1> kB{};
-    auto load_q = [&](Block &blk, auto bt, bool live) {
-        constexpr int bi = decltype(bt)::value;
+    auto load_q = [&](Block &blk, bool live) {
         const bool ok = live && blk.qrow < Sq;
         const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? blk.qrow : 0)) * Hq + hq) * kD + 8 * h;
-        u32x4 x[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            x[ks] = u32x4{0u, 0u, 0u, 0u};
-            if (ok) x[ks] = *reinterpret_cast<const u32x4 *>(qp + 16 * ks);
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (ok) x = *reinterpret_cast<const u32x4 *>(qp + 16 * ks);
+            blk.q[ks] = x;
         }
-        static_for<32>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            agpr_write<128 + 32 * bi + r>(x[r >> 2][r & 3]);
-        });
-        static_for<64>([&](auto R) { agpr_write<64 * bi + decltype(R)::value>(0u); });
         blk.m = -INFINITY;
         blk.l = 0.0f;
-    };
-    load_q(A, kA, nA > 0);
-    load_q(B, kB, nB > 0);
-
-    // ---- staging: thread handles rows st_row0 + 16i (i = 0..3), 16-byte chunk st_ch, of the K and
-    // of the V tile: 8 pieces per tile and thread (0..3 = K rows, 4..7 = V rows).  Buffer loads
-    // over this (batch, kv head)'s rows: the tile offset rides in the scalar offset (no address
-    // arithmetic per load) and rows past Skv read as zero (those keys are masked out of S in the
-    // block's last tile, so their P is exactly 0).
-    const int st_ch = tid & 15;
-    const int st_row0 = tid >> 4;
-    const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
-    const unsigned kv_bytes = (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
-    const int64_t head_off = ((int64_t)b * Skv * Hkv + kvh) * kD;
-    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(k + head_off), 0,
-                                                          (int)kv_bytes, 0x00020000);
-    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(v + head_off), 0,
-                                                          (int)kv_bytes, 0x00020000);
-    const unsigned st_voff = (unsigned)st_row0 * row_bytes + 16u * (unsigned)st_ch;
-    const unsigned st_kw = (unsigned)(kKBase + st_row0 * kKRow + 16 * st_ch);
-    const unsigned st_vw = (unsigned)(st_row0 * kVRow + 16 * (st_ch ^ (4 * (st_row0 & 3))));
-    u32x4 st[8];
-    // fetch piece j of key tile t
-    auto stage_l = [&](int t, int j) {
-        const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
-        st[j] = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc, st_voff, soff, 0));
-    };
-    // write piece j to K ring slot kslot / V ring slot vslot
-    auto stage_w = [&](int kslot, int vslot, int j) {
-        if (j < 4)
-            *reinterpret_cast<u32x4 *>(lds + st_kw + kslot * kKTile + j * 16 * kKRow) = st[j];
-        else
-            *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = st[j];
-    };
-    auto stage_load = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stage_l(t, j);
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) blk.acc[dt][r] = 0.0f;
+    };
+    load_q(A, nA > 0);
+    load_q(B, nB > 0);
+
+    // ---- staging: thread handles chunks idx = i*256 + tid (i = 0..3) of a 64 x 16-chunk tile
+    const int st_ch = tid & 15;
+    const int st_row0 = tid >> 4;  // + 16*i
+    const int64_t kv_row_stride = (int64_t)Hkv * kD;  // elements
+    const __bf16 *k_base = k + ((int64_t)b * Skv * Hkv + kvh) * kD + st_ch * 8;
+    const __bf16 *v_base = v + ((int64_t)b * Skv * Hkv + kvh) * kD + st_ch * 8;
+    u32x4 stk[4], stv[4];
+    auto stage_load = [&](int t) {
+        const int kv0 = t * kKV;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // rows past the end are clamped to the last row: always a valid, finite load; those
+            // keys are masked out of S in the block's last tile, so their P is exactly 0
+            int r = kv0 + st_row0 + 16 * i;
+            r = r < Skv ? r : Skv - 1;
+            stk[i] = *reinterpret_cast<const u32x4 *>(k_base + (int64_t)r * kv_row_stride);
+            stv[i] = *reinterpret_cast<const u32x4 *>(v_base + (int64_t)r * kv_row_stride);
+        }
     };
     auto stage_write = [&](int kslot, int vslot) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stage_w(kslot, vslot, j);
+        for (int i = 0; i < 4; ++i) {
+            const int r = st_row0 + 16 * i;
+            *reinterpret_cast<u32x4 *>(lds + kKBase + kslot * kKTile + r * kKRow + 16 * st_ch) = stk[i];
+            *reinterpret_cast<u32x4 *>(lds + vslot * kVTile + r * kVRow +
+                                       16 * (st_ch ^ (4 * (r & 3)))) = stv[i];
+        }
     };
 
     // ---- LDS read addresses
@@ -316,15 +243,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         v_rd[dt] = (unsigned)(v_row_in * kVRow + 8 * (pp & 1) + 16 * ((4 * dt + v_ch_lo) ^ v_sw));
 
     // fragment ring: the LDS reads run kPF MFMAs ahead of their use
-#ifndef K1_PF
-#define K1_PF 6
-#endif
-    constexpr int kPF = K1_PF, kRing = 8;  // kRing divides 16 and exceeds kPF
-    u32x4 fr[kRing];
+    constexpr int kPF = 3;
+    u32x4 fr[4];
     // K fragment of MFMA i (u = i>>3, ks = i&7) of a QK slot
     auto read_k = [&](int slot, int i) {
         const unsigned char *kt = lds + k_rd + slot * kKTile;
-        fr[i & (kRing - 1)] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
+        fr[i & 3] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
     };
     // V^T fragment of MFMA i (dt = i>>2, sp = i&3) of a PV slot
     auto read_v = [&](int slot, int i) {
@@ -332,7 +256,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kVRow));
         const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        fr[i & (kRing - 1)] = __builtin_bit_cast(u32x4, va);
+        fr[i & 3] = __builtin_bit_cast(u32x4, va);
     };
 
     // ---- vector-ALU steps of one item's softmax, cut so that they can be dealt out between MFMAs
@@ -359,9 +283,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         it.alpha = alpha;
         it.need = need;
         it.psum = 0.0f;
-        pin(it.mc);
-        pin(it.alpha);
-        pin(blk.l);
     };
     // element e of 32: p = exp2(s*c - m*c), row sum, bf16 pack of pairs
     auto exp_elem = [&](Item &it, int e) {
@@ -371,13 +292,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         if (e & 1) it.p[e >> 3][(e & 7) >> 1] = pack_bf16x2(it.hold, pe);
         else it.hold = pe;
     };
-    // O^T *= alpha: rare (deferred), so done register by register through the vector ALU
-    auto rescale = [&](const Item &it, auto bt) {
+    auto rescale = [&](const Item &it, Block &blk) {
         if (it.need) {
-            constexpr int bi = decltype(bt)::value;
-            const float f = it.alpha;
-            mfma_fence();
-            static_for<64>([&](auto R) { agpr_scale<64 * bi + decltype(R)::value>(f); });
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) blk.acc[dt] *= it.alpha;
             mfma_fence();
         }
     };
@@ -385,85 +303,63 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // its first kFirst elements
     constexpr int kFirst = 9;
     auto valu_pv = [&](Item &it, Block &blk, int i) {
-#ifdef K1_ABL_NOVALU
-        return;
-#endif
         if (i < 6) {
 #pragma unroll
             for (int j = 3 * i; j < 3 * i + 3; ++j)
                 if (j < 16) max_step(it, j);
-            pin(it.mx);
         } else if (i == 6) {
             decide(it, blk);
         } else {
             exp_elem(it, i - 7);
-            pin(it.psum, it.hold, it.p[(i - 7) >> 3]);
         }
     };
     // VALU share of slice i of a QK^T slot: the remaining 32 - kFirst elements of the other item
     auto valu_qk = [&](Item &it, Block &blk, int i) {
-#ifdef K1_ABL_NOVALU
-        return;
-#endif
         const int rest = 32 - kFirst;
         const int e0 = kFirst + (rest * i) / 16, e1 = kFirst + (rest * (i + 1)) / 16;
 #pragma unroll
         for (int e = e0; e < e1; ++e) exp_elem(it, e);
         if (i == 15) blk.l += it.psum;
-        pin(it.psum, it.hold, it.p[(e1 - 1) >> 3]);
-        if (i == 15) pin(blk.l);
     };
 
     // ---- pipelined slots: 16 slices of { MFMA ; LDS read kPF ahead ; a few VALU }.
     // next_rd(j) issues the read for MFMA j (j < kPF) of the slot that follows.
-    auto slot_qk = [&](Item &dst, auto bt, int kslot, auto &&valu, auto &&next_rd) {
-        constexpr int bi = decltype(bt)::value;
-        static_for<16>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr int qr = 128 + 32 * bi + 4 * (i & 7);
-            if constexpr ((i & 7) == 0) mfma_qk_first<qr>(i < 8 ? dst.sa : dst.sb, fr[i & (kRing - 1)]);
-            else mfma_qk<qr>(i < 8 ? dst.sa : dst.sb, fr[i & (kRing - 1)]);
-            if constexpr (i + kPF < 16) read_k(kslot, i + kPF);
+    auto slot_qk = [&](Item &dst, const Block &qb, int kslot, auto &&valu, auto &&next_rd) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((i & 7) == 0) mfma_qk_first(i < 8 ? dst.sa : dst.sb, fr[i & 3], qb.q[i & 7]);
+            else mfma_qk(i < 8 ? dst.sa : dst.sb, fr[i & 3], qb.q[i & 7]);
+            if (i + kPF < 16) read_k(kslot, i + kPF);
             else next_rd(i + kPF - 16);
             valu(i);
-#ifdef K1_DBG_FENCE
-            mfma_fence();
-#endif
-            // hipcc may copy the fresh scores right behind the last MFMA (it does not know the
-            // statement is one): keep the MFMA -> VALU wait states here, once per slot
-            if constexpr (i == 15) mfma_fence();
             __builtin_amdgcn_sched_barrier(0);
-        });
+        }
     };
-    auto slot_pv = [&](const Item &src, auto bt, int vslot, auto &&valu, auto &&next_rd) {
-        constexpr int bi = decltype(bt)::value;
-        static_for<16>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            mfma_pv<64 * bi + 16 * (i >> 2)>(fr[i & (kRing - 1)], src.p[i & 3]);
-            if constexpr (i + kPF < 16) read_v(vslot, i + kPF);
+    auto slot_pv = [&](const Item &src, Block &blk, int vslot, auto &&valu, auto &&next_rd) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mfma_pv(blk.acc[i >> 2], fr[i & 3], src.p[i & 3]);
+            if (i + kPF < 16) read_v(vslot, i + kPF);
             else next_rd(i + kPF - 16);
             valu(i);
-#ifdef K1_DBG_FENCE
-            mfma_fence();
-#endif
             __builtin_amdgcn_sched_barrier(0);
-        });
+        }
     };
     auto no_rd = [&](int) {};
     auto no_valu = [&](int) {};
 
     // ---- un-pipelined pieces (a block's last, masked key tile; pipeline drain)
-    auto qk_plain = [&](Item &it, auto bt, int kslot) {
+    auto qk_plain = [&](Item &it, const Block &blk, int kslot) {
 #pragma unroll
         for (int j = 0; j < kPF; ++j) read_k(kslot, j);
-        slot_qk(it, bt, kslot, no_valu, no_rd);
+        slot_qk(it, blk, kslot, no_valu, no_rd);
         mfma_fence();
     };
-    auto pv_plain = [&](const Item &it, auto bt, int vslot) {
+    auto pv_plain = [&](const Item &it, Block &blk, int vslot) {
 #pragma unroll
         for (int j = 0; j < kPF; ++j) read_v(vslot, j);
         mfma_fence();  // P was just written by the vector ALU
-        slot_pv(it, bt, vslot, no_valu, no_rd);
+        slot_pv(it, blk, vslot, no_valu, no_rd);
         mfma_fence();
     };
     // mask of a block's last key tile: key < Skv and (causal) key <= query row
@@ -489,23 +385,23 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         blk.l += it.psum;
     };
     // finish a pending item (its first kFirst elements are done), then its P.V
-    auto drain = [&](Item &it, Block &blk, auto bt, int vslot) {
+    auto drain = [&](Item &it, Block &blk, int vslot) {
         mfma_fence();
         softmax_plain(it, blk, kFirst);
-        rescale(it, bt);
-        pv_plain(it, bt, vslot);
+        rescale(it, blk);
+        pv_plain(it, blk, vslot);
     };
     // a block's last key tile, masked, un-pipelined
-    auto last_item = [&](Item &it, Block &blk, auto bt, int kslot, int vslot, int kv0) {
-        qk_plain(it, bt, kslot);
+    auto last_item = [&](Item &it, Block &blk, int kslot, int vslot, int kv0) {
+        qk_plain(it, blk, kslot);
         mask(it, blk, kv0);
         softmax_plain(it, blk, 0);
-        rescale(it, bt);
-        pv_plain(it, bt, vslot);
+        rescale(it, blk);
+        pv_plain(it, blk, vslot);
     };
     // an interior tile started un-pipelined: leaves the item pending with kFirst elements done
-    auto start_item = [&](Item &it, Block &blk, auto bt, int kslot) {
-        qk_plain(it, bt, kslot);
+    auto start_item = [&](Item &it, Block &blk, int kslot) {
+        qk_plain(it, blk, kslot);
 #pragma unroll
         for (int j = 0; j < 16; ++j) max_step(it, j);
         decide(it, blk);
@@ -525,6 +421,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     };
     clear_item(I0);
     clear_item(I1);
+    bool pend1 = true;  // the pending item lives in I1 (else I0)
 
     // ---- prologue: tile 0 into slot 0, V slot 2 ("tile -1") zeroed, tile 1 in flight
     stage_load(0);
@@ -535,146 +432,78 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
     }
     stage_write(0, 0);
-    stage_load(1);
+    if (nsteps > 1) stage_load(1);
     __syncthreads();
 
     int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
-    int ks_cur = 0;                            // K ring slot of tile t
-#ifdef NVLLM_K1_STAMPS
-    unsigned long long seg_sum[16] = {0}, t_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
-    // Every wave runs the same number of steps (nsteps), one barrier each, but walks them in its
-    // own phases -- separate loops, so that each hot loop is one straight body whose registers
-    // (scores, staging) have one definition per iteration.
-    int t = 0;
-    // end of a step: publish tile t+1 (written during this step), rotate the rings
-    auto step_end = [&]() {
+    for (int t = 0; t < nsteps; ++t) {
+        const int ks_cur = t & 1;
+        if (t + 1 < nsteps) stage_write(ks_cur ^ 1, vs_next);
+        if (t + 2 < nsteps) stage_load(t + 2);
+
+        if (t < nB - 1) {
+            // ---- both blocks, interior tile: A then B on the same keys
+#pragma unroll
+            for (int j = 0; j < kPF; ++j) read_k(ks_cur, j);
+            __builtin_amdgcn_sched_barrier(0);
+            slot_qk(I0, A, ks_cur, [&](int i) { valu_qk(I1, B, i); },
+                    [&](int j) { read_v(vs_prev, j); });
+            rescale(I1, B);
+            slot_pv(I1, B, vs_prev, [&](int i) { valu_pv(I0, A, i); },
+                    [&](int j) { read_k(ks_cur, j); });
+            slot_qk(I1, B, ks_cur, [&](int i) { valu_qk(I0, A, i); },
+                    [&](int j) { read_v(vs_cur, j); });
+            rescale(I0, A);
+            slot_pv(I0, A, vs_cur, [&](int i) { valu_pv(I1, B, i); }, no_rd);
+        } else if (t == nB - 1) {
+            // ---- block B's last tile: finish what is pending, then B and A un-pipelined
+            drain(I1, B, vs_prev);
+            last_item(I1, B, ks_cur, vs_cur, t * kKV);
+            if (t == nA - 1) {
+                last_item(I1, A, ks_cur, vs_cur, t * kKV);
+            } else {
+                start_item(I1, A, ks_cur);
+                pend1 = true;
+            }
+        } else if (t < nA - 1) {
+            // ---- block A alone, interior tile, alternating score register sets
+#pragma unroll
+            for (int j = 0; j < kPF; ++j) read_k(ks_cur, j);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pend1) {
+                slot_qk(I0, A, ks_cur, [&](int i) { valu_qk(I1, A, i); },
+                        [&](int j) { read_v(vs_prev, j); });
+                rescale(I1, A);
+                slot_pv(I1, A, vs_prev, [&](int i) { valu_pv(I0, A, i); }, no_rd);
+                pend1 = false;
+            } else {
+                slot_qk(I1, A, ks_cur, [&](int i) { valu_qk(I0, A, i); },
+                        [&](int j) { read_v(vs_prev, j); });
+                rescale(I0, A);
+                slot_pv(I0, A, vs_prev, [&](int i) { valu_pv(I1, A, i); }, no_rd);
+                pend1 = true;
+            }
+        } else if (t == nA - 1) {
+            // ---- block A's last tile
+            if (pend1) {
+                drain(I1, A, vs_prev);
+                last_item(I1, A, ks_cur, vs_cur, t * kKV);
+            } else {
+                drain(I0, A, vs_prev);
+                last_item(I0, A, ks_cur, vs_cur, t * kKV);
+            }
+        }
         __syncthreads();
-        K1_STAMP(11);  // barrier
-#ifdef NVLLM_K1_STAMPS
-        seg_sum[15] += 1;
-#endif
         const int x = vs_prev;
         vs_prev = vs_cur;
         vs_cur = vs_next;
         vs_next = x;
-        ks_cur ^= 1;
-        ++t;
-    };
-    // staging of a step, all at once (un-pipelined steps): tile t+1 (fetched during step t-1) goes
-    // to LDS, then tile t+2 is fetched into the same registers
-    auto stage_step = [&]() {
-        stage_write(ks_cur ^ 1, vs_next);
-        stage_load(t + 2);
-    };
-    // ... or dealt out over the MFMA gaps of the pipelined bodies
-#ifdef K1_ABL_NOSTAGE
-    auto st_dual_w = [&](int) {};
-    auto st_dual_l = [&](int) {};
-    auto st_one_w = [&](int) {};
-    auto st_one_l = [&](int) {};
-#else
-    auto st_dual_w = [&](int i) { if (i >= 8) stage_w(ks_cur ^ 1, vs_next, i - 8); };
-    auto st_dual_l = [&](int i) { if ((i & 1) == 0) stage_l(t + 2, i >> 1); };
-    auto st_one_w = [&](int i) { if (i >= 4 && i < 12) stage_w(ks_cur ^ 1, vs_next, i - 4); };
-    auto st_one_l = [&](int i) { if (i < 8) stage_l(t + 2, i); };
-#endif
-    auto prime_k = [&]() {
-#pragma unroll
-        for (int j = 0; j < kPF; ++j) read_k(ks_cur, j);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // block A alone, interior tile: QK^T into `nxt` while `cur` (pending) is finished and multiplied
-    auto single_step = [&](Item &cur, Item &nxt) {
-        prime_k();
-        slot_qk(nxt, kA, ks_cur, [&](int i) { valu_qk(cur, A, i); st_one_w(i); },
-                [&](int j) { read_v(vs_prev, j); });
-        K1_STAMP(5);
-        rescale(cur, kA);
-        slot_pv(cur, kA, vs_prev, [&](int i) { valu_pv(nxt, A, i); st_one_l(i); }, no_rd);
-        K1_STAMP(6);
-#ifdef NVLLM_K1_STAMPS
-        seg_sum[13] += 1;
-#endif
-        step_end();
-    };
-    auto final_step = [&](Item &cur) {
-        stage_step();
-        drain(cur, A, kA, vs_prev);
-        last_item(cur, A, kA, ks_cur, vs_cur, t * kKV);
-        K1_STAMP(8);
-        step_end();
-    };
-
-    // ---- phase 1: both blocks, interior tiles: A then B on the same keys
-    while (t < nB - 1) {
-        prime_k();
-        slot_qk(I0, kA, ks_cur, [&](int i) { valu_qk(I1, B, i); st_dual_w(i); },
-                [&](int j) { read_v(vs_prev, j); });
-        K1_STAMP(0);
-        rescale(I1, kB);
-        slot_pv(I1, kB, vs_prev, [&](int i) { valu_pv(I0, A, i); st_dual_l(i); },
-                [&](int j) { read_k(ks_cur, j); });
-        K1_STAMP(1);
-        slot_qk(I1, kB, ks_cur, [&](int i) { valu_qk(I0, A, i); },
-                [&](int j) { read_v(vs_cur, j); });
-        K1_STAMP(2);
-        rescale(I0, kA);
-        slot_pv(I0, kA, vs_cur, [&](int i) { valu_pv(I1, B, i); }, no_rd);
-        K1_STAMP(3);
-#ifdef NVLLM_K1_STAMPS
-        seg_sum[12] += 1;
-#endif
-        step_end();
-    }
-    // ---- block B's last tile: finish what is pending, then B and A un-pipelined
-    if (nB > 0) {
-        stage_step();
-        drain(I1, B, kB, vs_prev);
-        last_item(I1, B, kB, ks_cur, vs_cur, t * kKV);
-        if (t == nA - 1) last_item(I1, A, kA, ks_cur, vs_cur, t * kKV);
-        else start_item(I1, A, kA, ks_cur);
-        K1_STAMP(7);
-        step_end();
-    }
-    // ---- phase 2: block A alone, interior tiles, alternating the two score register sets
-    // (entered with the pending item, real or empty, in I1)
-    while (t + 1 < nA - 1) {
-        single_step(I1, I0);
-        single_step(I0, I1);
-    }
-    if (t < nA - 1) {
-        single_step(I1, I0);
-        if (t == nA - 1) final_step(I0);
-    } else if (t == nA - 1) {
-        final_step(I1);
-    }
-    // ---- steps this wave has no keys for (the workgroup's other waves do)
-    while (t < nsteps) {
-        stage_step();
-        K1_STAMP(9);
-        step_end();
     }
 
-#ifdef NVLLM_K1_STAMPS
-    if (lse && lane == 0) {
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(lse) +
-                                  ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 16);
-        for (int i = 0; i < 16; ++i) dbg[i] = seg_sum[i];
-    }
-    lse = nullptr;
-#endif
     // ---- epilogue: O^T lane (c,h) holds O[qrow][32dt + 8i + 4h + (0..3)] in regs 4i..4i+3
     mfma_fence();
-    auto store = [&](Block &blk, auto bt, bool live) {
-        constexpr int bi = decltype(bt)::value;
+    auto store = [&](Block &blk, bool live) {
         const float l = half_sum(blk.l);
-        float ov[64];
-        static_for<64>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            ov[r] = agpr_read<64 * bi + r>();
-        });
         if (live && blk.qrow < Sq) {
             const float inv = l > 0.0f ? 1.0f / l : 0.0f;
             __bf16 *op = o + (((int64_t)b * Sq + blk.qrow) * Hq + hq) * kD + 4 * h;
@@ -682,10 +511,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float *a4 = ov + 16 * dt + 4 * i;
                     u32x2 w;
-                    w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
-                    w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
+                    w[0] = pack_bf16x2(blk.acc[dt][4 * i] * inv, blk.acc[dt][4 * i + 1] * inv);
+                    w[1] = pack_bf16x2(blk.acc[dt][4 * i + 2] * inv, blk.acc[dt][4 * i + 3] * inv);
                     *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
                 }
             if (lse && h == 0)
@@ -693,8 +521,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     blk.m * scale_log2e * 0.6931471805599453f + logf(l);
         }
     };
-    store(A, kA, nA > 0);
-    store(B, kB, nB > 0);
+    store(A, nA > 0);
+    store(B, nB > 0);
 }
 
 }  // namespace
@@ -703,8 +531,6 @@ bool flash_attn_mfma_supported(const FlashAttnArgs &a) {
     if (a.head_dim != kD) return false;
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
     if (a.batch > 65535 || a.seq_q <= 0 || a.seq_kv <= 0) return false;
-    // K/V of one batch element are addressed with 32-bit buffer offsets
-    if ((int64_t)(a.seq_kv + 3 * kKV) * a.num_kv_heads * kD * 2 >= (int64_t)1 << 31) return false;
     const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     return al(a.q) && al(a.k) && al(a.v) && al(a.o);
 }

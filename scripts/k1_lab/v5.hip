@@ -429,9 +429,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef K1_DBG_FENCE
             mfma_fence();
 #endif
-            // hipcc may copy the fresh scores right behind the last MFMA (it does not know the
-            // statement is one): keep the MFMA -> VALU wait states here, once per slot
+#ifdef K1_DBG_FENCE_QKEND
             if constexpr (i == 15) mfma_fence();
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
