@@ -153,6 +153,20 @@ int main(int argc, char **argv) {
                 sum += e;
                 if (e > 2e-2) ++bad;
             }
+            if (getenv("LAB_ROWS")) {
+                printf("%-14s per 32-row block max err (b=0,h=0):", v.name);
+                for (int r0 = 0; r0 < S; r0 += 32) {
+                    double m = 0;
+                    for (int r = r0; r < r0 + 32 && r < S; ++r)
+                        for (int d = 0; d < D; ++d) {
+                            const size_t i = ((size_t)r * Hq + 0) * D + d;
+                            const double e = std::fabs((double)bf2f(hout[i]) - ref[i]);
+                            if (e > m || !(e == e)) m = e;
+                        }
+                    printf(" %.1e", m);
+                }
+                printf("\n");
+            }
             printf("%-14s check max_abs=%.3e mean_abs=%.3e bad=%zu worst@(b,s,h,d)=(%zu,%zu,%zu,%zu) %s\n",
                    v.name, mx, sum / nq, bad, worst / ((size_t)S * Hq * D), (worst / ((size_t)Hq * D)) % S,
                    (worst / D) % Hq, worst % D, (mx < 2e-2 && sum / nq < 1e-3) ? "OK" : "FAIL");

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4 *in, float *out, unsigne
     auto pk = [](float lo, float hi) { typedef __attribute__((ext_vector_type(2))) __bf16 b2; b2 r; r[0] = (__bf16)lo; r[1] = (__bf16)hi; return __builtin_bit_cast(unsigned, r); };
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    constexpr int UN = MODE == 22 ? 16 : MODE == 23 ? 64 : 1;
+#pragma unroll UN
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -81,6 +83,42 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4 *in, float *out, unsigne
                     f4[2] = __builtin_fmaf(f4[2], c0, c1); f4[3] = __builtin_fmaf(f4[3], c0, c1);
                     asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]));
                 }
+            } else if (MODE >= 13 && MODE <= 18) {
+                // C/D in AGPR (the P.V slot)
+                if (MODE == 13 || MODE == 16) {       // register operands
+                    asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" : : "v"(a), "v"(b));
+                } else {                // A from LDS by two transposed reads, 7 ahead
+                    asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" : : "v"(fr[i & 7]), "v"(b));
+                    typedef __attribute__((ext_vector_type(4))) short s4; typedef __attribute__((ext_vector_type(8))) short s8;
+                    typedef __attribute__((address_space(3))) s4 lds_s4;
+                    const int c16 = lane & 15, qq = c16 >> 2, pp = c16 & 3, g16 = lane >> 4, hh = lane >> 5;
+                    const int vrow = 4 * hh + qq, vsw = 4 * (vrow & 3), vlo = 2 * (g16 & 1) + (pp >> 1);
+                    const unsigned char *p0 = lds + vrow * 256 + 8 * (pp & 1) + 16 * ((4 * (((i + 7) >> 2) & 3) + vlo) ^ vsw) + 4096 * ((i + 7) & 3);
+                    s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)p0);
+                    s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(p0 + 2048));
+                    s8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    fr[(i + 7) & 7] = __builtin_bit_cast(u32x4, va);
+                }
+                if (MODE == 13 || MODE == 14) {       // 6 fma fillers
+                    for (int q = 0; q < 6; ++q) f4[q] = __builtin_fmaf(f4[q], c0, c1);
+                    asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]), "+v"(f4[4]), "+v"(f4[5]));
+                } else if (MODE == 17) {              // 1 element: fma, exp + half a cvt (approx)
+                    f4[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(f4[0], c0, c1));
+                    if (i & 1) pw = pk(f4[0], f4[1]);
+                    asm volatile("" : "+v"(f4[0]), "+v"(pw));
+                } else if (MODE == 18) {              // 3 fma fillers
+                    for (int q = 0; q < 3; ++q) f4[q] = __builtin_fmaf(f4[q], c0, c1);
+                    asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]));
+                }
+            } else if (MODE == 19) {  // register operands, D VGPR, 6 fma
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s0) : "v"(a), "v"(b));
+                for (int q = 0; q < 6; ++q) f4[q] = __builtin_fmaf(f4[q], c0, c1);
+                asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]), "+v"(f4[4]), "+v"(f4[5]));
+            } else if (MODE >= 20 && MODE <= 23) {  // b128 LDS-fed, acc AGPR, 6 fma / 3 fma
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" : : "v"(fr[i & 7]), "v"(b));
+                fr[(i + 7) & 7] = *reinterpret_cast<const u32x4 *>(lp + 32 * ((i + 7) & 7) + 8704 * ((it + i) & 1));
+                for (int q = 0; q < (MODE == 20 ? 6 : 3); ++q) f4[q] = __builtin_fmaf(f4[q], c0, c1);
+                asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]), "+v"(f4[4]), "+v"(f4[5]));
             } else if (MODE == 6) {  // builtin, compiler-scheduled
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
                                                               __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), s0, 0, 0, 0);
@@ -135,6 +173,17 @@ int main() {
         if (run<10>("LDS-fed + 4 fma, 4 pins", din, dout, dc, grid)) return 1;
         if (run<11>("LDS-fed + 6 fma, 1 pin", din, dout, dc, grid)) return 1;
         if (run<12>("LDS-fed + 2 exp + 2 fma, 1 pin", din, dout, dc, grid)) return 1;
+        if (run<19>("regs, D VGPR + 6 fma", din, dout, dc, grid)) return 1;
+        if (run<20>("b128 LDS-fed, acc AGPR + 6 fma", din, dout, dc, grid)) return 1;
+        if (run<21>("b128 LDS-fed, acc AGPR + 3 fma", din, dout, dc, grid)) return 1;
+        if (run<22>("  same, body unrolled to 256 slices", din, dout, dc, grid)) return 1;
+        if (run<23>("  same, body unrolled to 1024 slices", din, dout, dc, grid)) return 1;
+        if (run<13>("acc AGPR, regs + 6 fma", din, dout, dc, grid)) return 1;
+        if (run<14>("acc AGPR, tr-read fed + 6 fma", din, dout, dc, grid)) return 1;
+        if (run<15>("acc AGPR, tr-read fed", din, dout, dc, grid)) return 1;
+        if (run<16>("acc AGPR, regs", din, dout, dc, grid)) return 1;
+        if (run<17>("acc AGPR, tr-read fed + 1 elem", din, dout, dc, grid)) return 1;
+        if (run<18>("acc AGPR, tr-read fed + 3 fma", din, dout, dc, grid)) return 1;
     }
     return 0;
 }

@@ -112,7 +112,6 @@ struct Item {
     u32x4 p[4];     // P^T B fragments, k-step 2u + sh
     float mc;       // reference max * scale * log2(e)
     float alpha;    // pending O rescale factor
-    float psum;     // partial row sum
     float mx;       // running max of the raw scores
     float hold;     // even element waiting for its pair (bf16 packing)
     bool need;      // wave-uniform: alpha != 1
@@ -122,14 +121,18 @@ struct Item {
 // accumulator half of the register file under LITERAL names, out of the compiler's sight:
 //   O^T of block b, d-tile dt : a[64b + 16dt : 64b + 16dt + 15]
 //   Q^T of block b, k-step ks : a[128 + 32b + 4ks : 128 + 32b + 4ks + 3]
+//   row sums l of block b     : a[192 + 16b : 192 + 16b + 15]  (ones . P^T, every register the same)
 // so that the vector ALU half (256 registers) is left to the softmax and the staging.  The
 // compiler never spills (checked at build time: zero spills, no v_accvgpr outside the asm
-// statements), so nothing else ever lands in a[0:191].
+// statements), so nothing else ever lands in a[0:223].
 struct Block {
-    float m, l;
+    float m;   // reference max of the running softmax
+#ifdef K1_DBG_VALU_L
+    float l;
+#endif
     int qrow;  // this lane's query row
 };
-#define K1_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
+#define K1_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
 
 template <int I> using ic = std::integral_constant<int, I>;
 template <int... Is, class F>
@@ -144,20 +147,48 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
 // schedules around them nor pads their hazards (cdna_hip_programming.md 5.7): every VALU read of
 // an MFMA result below sits at least 12 wait states after the MFMA, by construction in the
 // pipelined bodies and by mfma_fence() elsewhere.
-template <int QR>
-__device__ __forceinline__ void mfma_qk_first(f32x16 &s, const u32x4 &kf) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
-                 : "=&v"(s) : "v"(kf), "i"(QR), "i"(QR + 3) : K1_AGPRS);
+// Every MFMA statement also takes the softmax values the vector ALU has produced so far (Deps) as
+// unused inputs: that pins the vector-ALU work of an MFMA gap in front of the next MFMA (hipcc
+// would otherwise sink the exponentials to their first use, a whole slot later), at no
+// instruction cost.  The first MFMA of a 4-fragment group names the group's other three fragments
+// the same way, so that one s_waitcnt covers the group.
+struct Deps {
+    float a, b, c;
+    u32x4 p0, p1, p2, p3;
+};
+#define K1_DEPS(d) "v"(d.a), "v"(d.b), "v"(d.c), "v"(d.p0), "v"(d.p1), "v"(d.p2), "v"(d.p3)
+template <int QR, bool FIRST>
+__device__ __forceinline__ void mfma_qk(f32x16 &s, const u32x4 &kf, const Deps &d) {
+    if constexpr (FIRST)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
+                     : "=&v"(s) : "v"(kf), "i"(QR), "i"(QR + 3), K1_DEPS(d) : K1_AGPRS);
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
+                     : "+v"(s) : "v"(kf), "i"(QR), "i"(QR + 3), K1_DEPS(d) : K1_AGPRS);
 }
-template <int QR>
-__device__ __forceinline__ void mfma_qk(f32x16 &s, const u32x4 &kf) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
-                 : "+v"(s) : "v"(kf), "i"(QR), "i"(QR + 3) : K1_AGPRS);
+template <int QR, bool FIRST>
+__device__ __forceinline__ void mfma_qk_g(f32x16 &s, const u32x4 &kf, const u32x4 &f1,
+                                          const u32x4 &f2, const u32x4 &f3, const Deps &d) {
+    if constexpr (FIRST)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0"
+                     : "=&v"(s) : "v"(kf), "i"(QR), "i"(QR + 3), "v"(f1), "v"(f2), "v"(f3), K1_DEPS(d)
+                     : K1_AGPRS);
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0"
+                     : "+v"(s) : "v"(kf), "i"(QR), "i"(QR + 3), "v"(f1), "v"(f2), "v"(f3), K1_DEPS(d)
+                     : K1_AGPRS);
 }
 template <int AR>
-__device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &p) {
+__device__ __forceinline__ void mfma_pv(const u32x4 &vf, const u32x4 &p, const Deps &d) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
-                 : : "v"(vf), "v"(p), "i"(AR), "i"(AR + 15) : K1_AGPRS);
+                 : : "v"(vf), "v"(p), "i"(AR), "i"(AR + 15), K1_DEPS(d) : K1_AGPRS);
+}
+template <int AR>
+__device__ __forceinline__ void mfma_pv_g(const u32x4 &vf, const u32x4 &p, const u32x4 &f1,
+                                          const u32x4 &f2, const u32x4 &f3, const Deps &d) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
+                 : : "v"(vf), "v"(p), "i"(AR), "i"(AR + 15), "v"(f1), "v"(f2), "v"(f3), K1_DEPS(d)
+                 : K1_AGPRS);
 }
 template <int R> __device__ __forceinline__ void agpr_write(unsigned x) {
     asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(x), "i"(R));
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     Block A, B;
     A.qrow = rowA0 + c;
     B.qrow = rowB0 + c;
-    // reserves a[0:191] in the kernel descriptor; every later statement names them literally
+    // reserves a[0:223] in the kernel descriptor; every later statement names them literally
     asm volatile("" ::: K1_AGPRS);
     constexpr ic<0> kA{};
     constexpr ic<1> kB{};
@@ -255,8 +286,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             agpr_write<128 + 32 * bi + r>(x[r >> 2][r & 3]);
         });
         static_for<64>([&](auto R) { agpr_write<64 * bi + decltype(R)::value>(0u); });
+        static_for<16>([&](auto R) { agpr_write<192 + 16 * bi + decltype(R)::value>(0u); });
         blk.m = -INFINITY;
-        blk.l = 0.0f;
     };
     load_q(A, kA, nA > 0);
     load_q(B, kB, nB > 0);
@@ -315,26 +346,34 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     for (int dt = 0; dt < 4; ++dt)
         v_rd[dt] = (unsigned)(v_row_in * kVRow + 8 * (pp & 1) + 16 * ((4 * dt + v_ch_lo) ^ v_sw));
 
-    // fragment ring: the LDS reads run kPF MFMAs ahead of their use
-#ifndef K1_PF
-#define K1_PF 6
-#endif
-    constexpr int kPF = K1_PF, kRing = 8;  // kRing divides 16 and exceeds kPF
-    u32x4 fr[kRing];
-    // K fragment of MFMA i (u = i>>3, ks = i&7) of a QK slot
+    // fragment ring: two groups of four fragments; a group's LDS reads are issued while the group
+    // before it is multiplied
+    u32x4 fr[8];
+    // K fragment i (u = i>>3, ks = i&7) of a QK slot
     auto read_k = [&](int slot, int i) {
         const unsigned char *kt = lds + k_rd + slot * kKTile;
-        fr[i & (kRing - 1)] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
+        fr[i & 7] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
     };
-    // V^T fragment of MFMA i (dt = i>>2, sp = i&3) of a PV slot
+    // V^T fragment i (dt = i>>2, sp = i&3) of a PV slot
     auto read_v = [&](int slot, int i) {
         const unsigned char *p0 = lds + slot * kVTile + v_rd[i >> 2] + (i & 3) * 16 * kVRow;
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kVRow));
         const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        fr[i & (kRing - 1)] = __builtin_bit_cast(u32x4, va);
+        fr[i & 7] = __builtin_bit_cast(u32x4, va);
     };
+    // bf16 1.0 x 8, made once and opaque: a constant hipcc re-creates with v_mov right in front of
+    // the MFMA statement would be read before it has landed (VALU write -> MFMA operand hazard)
+    u32x4 ones;
+    asm volatile("v_mov_b32 %0, 0x3f803f80" : "=v"(ones[0]));
+    ones[1] = ones[0];
+    ones[2] = ones[0];
+    ones[3] = ones[0];
+    asm volatile("" : "+v"(ones));
 
+#ifdef K1_DBG_VALU_L
+    float dbg_l = 0.f;  // only valid for single-block (nB == 0) waves without rescale
+#endif
     // ---- vector-ALU steps of one item's softmax, cut so that they can be dealt out between MFMAs
     // running max, step j of 16: sa pairs first (their MFMAs finished long ago), then sb pairs
     auto max_step = [&](Item &it, int j) {
@@ -343,7 +382,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         else if (j < 8) it.mx = fmaxf(fmaxf(it.mx, it.sa[r]), it.sa[r + 1]);
         else it.mx = fmaxf(fmaxf(it.mx, it.sb[r]), it.sb[r + 1]);
     };
-    // deferred-rescale decision (wave-uniform), new reference max; l is rescaled here, O later
+    // deferred-rescale decision (wave-uniform), new reference max; O and l are rescaled later
     // (just before this item's P.V)
     auto decide = [&](Item &it, Block &blk) {
         const float mx = half_max(it.mx);
@@ -354,98 +393,115 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
         const float alpha = need ? fast_exp2((blk.m - m_safe) * scale_log2e) : 1.0f;
         blk.m = m_new;
-        blk.l *= alpha;
         it.mc = m_safe * scale_log2e;
         it.alpha = alpha;
         it.need = need;
-        it.psum = 0.0f;
-        pin(it.mc);
-        pin(it.alpha);
-        pin(blk.l);
     };
-    // element e of 32: p = exp2(s*c - m*c), row sum, bf16 pack of pairs
+    // element e of 32: p = exp2(s*c - m*c), bf16 pack of pairs (the row sum is an MFMA: ones . P^T)
     auto exp_elem = [&](Item &it, int e) {
         const float s = e < 16 ? it.sa[e & 15] : it.sb[e & 15];
         const float pe = fast_exp2(__builtin_fmaf(s, scale_log2e, -it.mc));
-        it.psum += pe;
         if (e & 1) it.p[e >> 3][(e & 7) >> 1] = pack_bf16x2(it.hold, pe);
         else it.hold = pe;
+#ifdef K1_DBG_VALU_L
+        dbg_l += pe;
+#endif
     };
-    // O^T *= alpha: rare (deferred), so done register by register through the vector ALU
+    auto deps_of = [&](const Item &it) {
+        return Deps{it.mx, it.mc, it.hold, it.p[0], it.p[1], it.p[2], it.p[3]};
+    };
+    // O^T *= alpha, l *= alpha: rare (deferred), so done register by register through the vector ALU
     auto rescale = [&](const Item &it, auto bt) {
         if (it.need) {
             constexpr int bi = decltype(bt)::value;
             const float f = it.alpha;
             mfma_fence();
             static_for<64>([&](auto R) { agpr_scale<64 * bi + decltype(R)::value>(f); });
+            static_for<16>([&](auto R) { agpr_scale<192 + 16 * bi + decltype(R)::value>(f); });
             mfma_fence();
         }
     };
-    // VALU share of slice i of a P.V slot: statistics of the item whose QK^T just finished, then
-    // its first kFirst elements
-    constexpr int kFirst = 9;
+    // VALU share of slice i (of 20) of a P.V slot: statistics of the item whose QK^T just
+    // finished, then its first kFirst elements
+    constexpr int kFirst = 15;
     auto valu_pv = [&](Item &it, Block &blk, int i) {
 #ifdef K1_ABL_NOVALU
         return;
 #endif
-        if (i < 6) {
+        if (i < 4) {
 #pragma unroll
-            for (int j = 3 * i; j < 3 * i + 3; ++j)
-                if (j < 16) max_step(it, j);
-            pin(it.mx);
-        } else if (i == 6) {
+            for (int j = 4 * i; j < 4 * i + 4; ++j) max_step(it, j);
+        } else if (i == 4) {
             decide(it, blk);
         } else {
-            exp_elem(it, i - 7);
-            pin(it.psum, it.hold, it.p[(i - 7) >> 3]);
+            exp_elem(it, i - 5);
         }
     };
-    // VALU share of slice i of a QK^T slot: the remaining 32 - kFirst elements of the other item
-    auto valu_qk = [&](Item &it, Block &blk, int i) {
+    // VALU share of slice i (of 16) of a QK^T slot: the remaining 17 elements of the other item
+    auto valu_qk = [&](Item &it, int i) {
 #ifdef K1_ABL_NOVALU
         return;
 #endif
-        const int rest = 32 - kFirst;
-        const int e0 = kFirst + (rest * i) / 16, e1 = kFirst + (rest * (i + 1)) / 16;
-#pragma unroll
-        for (int e = e0; e < e1; ++e) exp_elem(it, e);
-        if (i == 15) blk.l += it.psum;
-        pin(it.psum, it.hold, it.p[(e1 - 1) >> 3]);
-        if (i == 15) pin(blk.l);
+        exp_elem(it, kFirst + i);
+        if (i == 15) exp_elem(it, 31);
     };
 
-    // ---- pipelined slots: 16 slices of { MFMA ; LDS read kPF ahead ; a few VALU }.
-    // next_rd(j) issues the read for MFMA j (j < kPF) of the slot that follows.
-    auto slot_qk = [&](Item &dst, auto bt, int kslot, auto &&valu, auto &&next_rd) {
+    // ---- pipelined slots.  Slice = { MFMA ; LDS reads ; a few VALU }.  Fragment group g + 1 is read
+    // during the first two slices of group g; next_rd(j) issues the read of fragment j (j < 4) of
+    // the slot that follows.  `work` is the item whose softmax runs in this slot's MFMA gaps.
+    auto slot_qk = [&](Item &dst, auto bt, int kslot, const Item &work, auto &&valu, auto &&next_rd) {
         constexpr int bi = decltype(bt)::value;
         static_for<16>([&](auto I) {
             constexpr int i = decltype(I)::value;
             constexpr int qr = 128 + 32 * bi + 4 * (i & 7);
-            if constexpr ((i & 7) == 0) mfma_qk_first<qr>(i < 8 ? dst.sa : dst.sb, fr[i & (kRing - 1)]);
-            else mfma_qk<qr>(i < 8 ? dst.sa : dst.sb, fr[i & (kRing - 1)]);
-            if constexpr (i + kPF < 16) read_k(kslot, i + kPF);
-            else next_rd(i + kPF - 16);
-            valu(i);
+            constexpr int g0 = (i & 4);  // ring half of this group
+            const Deps d = deps_of(work);
+            if constexpr ((i & 3) == 0)
+                mfma_qk_g<qr, (i & 7) == 0>(i < 8 ? dst.sa : dst.sb, fr[g0], fr[g0 + 1], fr[g0 + 2],
+                                            fr[g0 + 3], d);
+            else
+                mfma_qk<qr, false>(i < 8 ? dst.sa : dst.sb, fr[i & 7], d);
+            if constexpr ((i & 3) < 2) {
+                constexpr int j0 = (i & ~3) + 4 + 2 * (i & 3);  // two fragments of the next group
+                if constexpr (j0 < 16) { read_k(kslot, j0); read_k(kslot, j0 + 1); }
+                else { next_rd(j0 - 16); next_rd(j0 - 15); }
+            }
 #ifdef K1_DBG_FENCE
             mfma_fence();
 #endif
-#ifdef K1_DBG_FENCE_QKEND
+            valu(i);
+            // hipcc may copy the fresh scores right behind the last MFMA (it does not know the
+            // statement is one): keep the MFMA -> VALU wait states here, once per slot
             if constexpr (i == 15) mfma_fence();
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    auto slot_pv = [&](const Item &src, auto bt, int vslot, auto &&valu, auto &&next_rd) {
+    // O^T += V^T P^T (16 MFMAs) and l += ones P^T (4 MFMAs) for the item `src`
+    auto slot_pv = [&](const Item &src, auto bt, int vslot, const Item &work, auto &&valu,
+                       auto &&next_rd) {
         constexpr int bi = decltype(bt)::value;
-        static_for<16>([&](auto I) {
+        static_for<20>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            mfma_pv<64 * bi + 16 * (i >> 2)>(fr[i & (kRing - 1)], src.p[i & 3]);
-            if constexpr (i + kPF < 16) read_v(vslot, i + kPF);
-            else next_rd(i + kPF - 16);
-            valu(i);
+            const Deps d = deps_of(work);
+            if constexpr (i < 16) {
+                constexpr int g0 = (i & 4);
+                constexpr int ar = 64 * bi + 16 * (i >> 2);
+                if constexpr ((i & 3) == 0)
+                    mfma_pv_g<ar>(fr[g0], src.p[0], fr[g0 + 1], fr[g0 + 2], fr[g0 + 3], d);
+                else
+                    mfma_pv<ar>(fr[i & 7], src.p[i & 3], d);
+                if constexpr ((i & 3) < 2) {
+                    constexpr int j0 = (i & ~3) + 4 + 2 * (i & 3);
+                    if constexpr (j0 < 16) { read_v(vslot, j0); read_v(vslot, j0 + 1); }
+                    else { next_rd(j0 - 16); next_rd(j0 - 15); }
+                }
+            } else {
+                mfma_pv<192 + 16 * bi>(ones, src.p[i & 3], d);
+            }
 #ifdef K1_DBG_FENCE
             mfma_fence();
 #endif
+            valu(i);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -455,17 +511,17 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // ---- un-pipelined pieces (a block's last, masked key tile; pipeline drain)
     auto qk_plain = [&](Item &it, auto bt, int kslot) {
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) read_k(kslot, j);
-        slot_qk(it, bt, kslot, no_valu, no_rd);
+        for (int j = 0; j < 4; ++j) read_k(kslot, j);
+        slot_qk(it, bt, kslot, it, no_valu, no_rd);
         mfma_fence();
     };
     auto pv_plain = [&](Item &it, auto bt, int vslot) {
         // P must be complete before the fence below (VALU write -> MFMA operand wait states)
         asm volatile("" : "+v"(it.p[0]), "+v"(it.p[1]), "+v"(it.p[2]), "+v"(it.p[3]));
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) read_v(vslot, j);
+        for (int j = 0; j < 4; ++j) read_v(vslot, j);
         mfma_fence();  // P was just written by the vector ALU
-        slot_pv(it, bt, vslot, no_valu, no_rd);
+        slot_pv(it, bt, vslot, it, no_valu, no_rd);
         mfma_fence();
     };
     // mask of a block's last key tile: key < Skv and (causal) key <= query row
@@ -488,7 +544,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 32; ++e)
             if (e >= e_from) exp_elem(it, e);
-        blk.l += it.psum;
     };
     // finish a pending item (its first kFirst elements are done), then its P.V
     auto drain = [&](Item &it, Block &blk, auto bt, int vslot) {
@@ -522,7 +577,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         for (int r = 0; r < 16; ++r) { it.sa[r] = -INFINITY; it.sb[r] = -INFINITY; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) it.p[i] = u32x4{0u, 0u, 0u, 0u};
-        it.mc = 0.0f; it.alpha = 1.0f; it.psum = 0.0f; it.need = false; it.mx = -INFINITY;
+        it.mc = 0.0f; it.alpha = 1.0f; it.need = false; it.mx = -INFINITY;
         it.hold = 0.0f;
     };
     clear_item(I0);
@@ -571,30 +626,28 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         stage_load(t + 2);
     };
     // ... or dealt out over the MFMA gaps of the pipelined bodies
+    // ... or dealt out over the MFMA gaps of the pipelined bodies, into slices that issue no
+    // fragment reads (2, 3 mod 4, and the four l slices of a P.V slot)
 #ifdef K1_ABL_NOSTAGE
-    auto st_dual_w = [&](int) {};
-    auto st_dual_l = [&](int) {};
-    auto st_one_w = [&](int) {};
-    auto st_one_l = [&](int) {};
+    auto st_w8 = [&](int) {};
+    auto st_l8 = [&](int) {};
 #else
-    auto st_dual_w = [&](int i) { if (i >= 8) stage_w(ks_cur ^ 1, vs_next, i - 8); };
-    auto st_dual_l = [&](int i) { if ((i & 1) == 0) stage_l(t + 2, i >> 1); };
-    auto st_one_w = [&](int i) { if (i >= 4 && i < 12) stage_w(ks_cur ^ 1, vs_next, i - 4); };
-    auto st_one_l = [&](int i) { if (i < 8) stage_l(t + 2, i); };
+    auto st_w8 = [&](int i) { if ((i & 2) && i < 16) stage_w(ks_cur ^ 1, vs_next, (i >> 2) * 2 + (i & 1)); };
+    auto st_l8 = [&](int i) { if ((i & 2) && i < 16) stage_l(t + 2, (i >> 2) * 2 + (i & 1)); };
 #endif
     auto prime_k = [&]() {
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) read_k(ks_cur, j);
+        for (int j = 0; j < 4; ++j) read_k(ks_cur, j);
         __builtin_amdgcn_sched_barrier(0);
     };
     // block A alone, interior tile: QK^T into `nxt` while `cur` (pending) is finished and multiplied
     auto single_step = [&](Item &cur, Item &nxt) {
         prime_k();
-        slot_qk(nxt, kA, ks_cur, [&](int i) { valu_qk(cur, A, i); st_one_w(i); },
+        slot_qk(nxt, kA, ks_cur, cur, [&](int i) { valu_qk(cur, i); st_w8(i); },
                 [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(5);
         rescale(cur, kA);
-        slot_pv(cur, kA, vs_prev, [&](int i) { valu_pv(nxt, A, i); st_one_l(i); }, no_rd);
+        slot_pv(cur, kA, vs_prev, nxt, [&](int i) { valu_pv(nxt, A, i); st_l8(i); }, no_rd);
         K1_STAMP(6);
 #ifdef NVLLM_K1_STAMPS
         seg_sum[13] += 1;
@@ -612,18 +665,18 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // ---- phase 1: both blocks, interior tiles: A then B on the same keys
     while (t < nB - 1) {
         prime_k();
-        slot_qk(I0, kA, ks_cur, [&](int i) { valu_qk(I1, B, i); st_dual_w(i); },
+        slot_qk(I0, kA, ks_cur, I1, [&](int i) { valu_qk(I1, i); st_w8(i); },
                 [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(0);
         rescale(I1, kB);
-        slot_pv(I1, kB, vs_prev, [&](int i) { valu_pv(I0, A, i); st_dual_l(i); },
+        slot_pv(I1, kB, vs_prev, I0, [&](int i) { valu_pv(I0, A, i); st_l8(i); },
                 [&](int j) { read_k(ks_cur, j); });
         K1_STAMP(1);
-        slot_qk(I1, kB, ks_cur, [&](int i) { valu_qk(I0, A, i); },
+        slot_qk(I1, kB, ks_cur, I0, [&](int i) { valu_qk(I0, i); },
                 [&](int j) { read_v(vs_cur, j); });
         K1_STAMP(2);
         rescale(I0, kA);
-        slot_pv(I0, kA, vs_cur, [&](int i) { valu_pv(I1, B, i); }, no_rd);
+        slot_pv(I0, kA, vs_cur, I1, [&](int i) { valu_pv(I1, B, i); }, no_rd);
         K1_STAMP(3);
 #ifdef NVLLM_K1_STAMPS
         seg_sum[12] += 1;
@@ -671,7 +724,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     mfma_fence();
     auto store = [&](Block &blk, auto bt, bool live) {
         constexpr int bi = decltype(bt)::value;
-        const float l = half_sum(blk.l);
+        float l = agpr_read<192 + 16 * bi>();
+#ifdef K1_DBG_VALU_L
+        if (bi == 0 && nB == 0) l = half_sum(dbg_l);
+#endif
         float ov[64];
         static_for<64>([&](auto R) {
             constexpr int r = decltype(R)::value;

@@ -1,0 +1,32 @@
+"""Build-time audit of the K1 flash-attention kernel's ISA (no GPU needed).
+
+K1 keeps its accumulators and Q fragments in literally named AGPRs and issues its MFMAs as
+inline asm, which hipcc neither schedules around nor pads hazards for.  The audit
+(scripts/k1_lab/check_asm.py) compiles nothing itself; this test cross-compiles the kernel to
+gfx950 assembly and requires: no compiler-generated use of the owned AGPR range outside the asm
+statements, no register spills, and no VALU write of an MFMA operand within the two
+instructions in front of an MFMA statement."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_k1_isa_audit(tmp_path):
+    src = os.path.join(ROOT, "nano-vllm-rs_amd", "csrc", "flash_attn_mfma.hip")
+    out = str(tmp_path / "k1.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-I" + os.path.join(ROOT, "nano-vllm-rs_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), "-x", "hip",
+                           "--cuda-device-only", "-S", src, "-o", out])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "k1_lab", "check_asm.py"), out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = r.stdout
+    assert ".vgpr_spill_count: 0" in text
+    assert ".private_segment_fixed_size: 0" in text
