@@ -171,6 +171,27 @@ def test_shared_prefix_blocks_and_spec_verify(dev):
     assert_attention_close(got, want)
 
 
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("prefix_blocks,splits", [(0, 1), (1, 1), (5, 1), (8, 2), (11, 3), (40, 1)])
+def test_adaptive_cache_policy_is_invisible(dev, monkeypatch, nt, prefix_blocks, splits):
+    # K2 reads a shared leading prefix with the default cache policy and everything after it
+    # non-temporally, in two separate tile loops; the switch-over tile (odd prefix lengths fall
+    # in the middle of a 2-block tile), split boundaries and an odd sequence count (the last
+    # sequence has no neighbour) must all give the oracle's result, with the policy on or off
+    monkeypatch.setenv("NVLLM_PAGED_NT", str(nt))
+    monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
+    Hq, Hkv, D, bs, T = 32, 8, 128, 16, 1
+    rng = np.random.default_rng(100 + prefix_blocks)
+    ctx_lens = [700, 650, 1000, 777, 16 * prefix_blocks + 5 if prefix_blocks else 40, 900, 333]
+    kc, vc, tables = make_paged_case(rng, ctx_lens, 500, bs, Hkv, D,
+                                     shared_prefix_blocks=prefix_blocks)
+    q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
+    scale = 1.0 / math.sqrt(D)
+    got = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale, max_blocks=64)
+    want = oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, scale)
+    assert_attention_close(got, want)
+
+
 def test_zero_context_rows_are_zero(dev):
     Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(0)
