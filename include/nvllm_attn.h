@@ -226,6 +226,34 @@ void nvllm_block_manager_reset(nvllm_block_manager *m);                         
 /* Reference-shaped operators (one sequence per call, host BlockTable)       */
 /* ======================================================================== */
 
+/* --- batched step metadata -------------------------------------------------
+ * Replaces, for the batched kernels, the per-sequence hand-off of the reference's scheduler
+ * (src/scheduler/batch.rs:227-375 -> one BlockTable per paged_attention call,
+ * src/attention/paged.rs:117-192): the scheduled sequences of one step are flattened into
+ * block_tables int32 [num_seqs, max_blocks_per_seq], context_lens int32 [num_seqs] (context
+ * including the new tokens), slot_mapping int64 [num_tokens] (block.rs:269-283 arithmetic for
+ * the new tokens, in order) and query_start int32 [num_seqs + 1].  Host only; _upload copies the
+ * four arrays to caller-allocated device buffers on `stream`. */
+typedef struct nvllm_batch nvllm_batch;
+nvllm_batch *nvllm_batch_new(int64_t max_blocks_per_seq);
+void nvllm_batch_free(nvllm_batch *b);
+void nvllm_batch_clear(nvllm_batch *b);
+/* NVLLM_ERR_CONFIG: num_new_tokens > context_len, context_len beyond the table's blocks
+ * (paged.rs:150 narrow), table longer than max_blocks_per_seq */
+int nvllm_batch_add_sequence(nvllm_batch *b, const nvllm_block_table *t, int64_t context_len,
+                             int64_t num_new_tokens);
+int64_t nvllm_batch_num_seqs(const nvllm_batch *b);
+int64_t nvllm_batch_num_tokens(const nvllm_batch *b);
+int64_t nvllm_batch_max_blocks_per_seq(const nvllm_batch *b);
+const int32_t *nvllm_batch_block_tables(const nvllm_batch *b);
+const int32_t *nvllm_batch_context_lens(const nvllm_batch *b);
+const int64_t *nvllm_batch_slot_mapping(const nvllm_batch *b);
+const int32_t *nvllm_batch_query_start(const nvllm_batch *b);
+/* any destination may be NULL (skipped); the copies are issued on `stream` and complete before
+ * the call returns (the host arrays are pageable) */
+int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_context_lens,
+                       void *d_slot_mapping, void *d_query_start, nvllm_stream_t stream);
+
 /* paged_attention exactly as src/attention/paged.rs:117-126 takes it: one
  * sequence, a host BlockTable, the layer's cache.  Validates like the
  * reference (empty table -> NVLLM_ERR_CONFIG, paged.rs:133-137; batch != 1 or

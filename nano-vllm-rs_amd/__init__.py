@@ -11,7 +11,7 @@ this package falls back to PyTorch or to the CPU oracle.
 from . import capi  # noqa: F401
 from . import sharding  # noqa: F401
 from .core import (  # noqa: F401
-    DEFAULT_BLOCK_SIZE, BlockTable, BlockManager, KVCacheConfig, LayerKVCache, KVCache,
+    DEFAULT_BLOCK_SIZE, BlockTable, BlockManager, BatchMetadata, KVCacheConfig, LayerKVCache, KVCache,
     compute_num_blocks, hash_token_block, NvllmError, ConfigError, OutOfBlocksError,
     BlockIndexOutOfBoundsError, TensorError,
 )

@@ -50,6 +50,18 @@ SIGNATURES = {
     "nvllm_block_table_get_block_id": (_i, [_vp, _i64, _pi64]),
     "nvllm_block_table_get_physical_block_ids": (_i64, [_vp, _pi64, _i64]),
     "nvllm_block_table_get_slot_mapping": (_i64, [_vp, _i64, _pi64, _i64]),
+    "nvllm_batch_new": (_vp, [_i64]),
+    "nvllm_batch_free": (None, [_vp]),
+    "nvllm_batch_clear": (None, [_vp]),
+    "nvllm_batch_add_sequence": (_i, [_vp, _vp, _i64, _i64]),
+    "nvllm_batch_num_seqs": (_i64, [_vp]),
+    "nvllm_batch_num_tokens": (_i64, [_vp]),
+    "nvllm_batch_max_blocks_per_seq": (_i64, [_vp]),
+    "nvllm_batch_block_tables": (_vp, [_vp]),
+    "nvllm_batch_context_lens": (_vp, [_vp]),
+    "nvllm_batch_slot_mapping": (_vp, [_vp]),
+    "nvllm_batch_query_start": (_vp, [_vp]),
+    "nvllm_batch_upload": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "nvllm_block_manager_new": (_vp, [_i64, _i64]),
     "nvllm_block_manager_free_handle": (None, [_vp]),
     "nvllm_block_manager_block_size": (_i64, [_vp]),

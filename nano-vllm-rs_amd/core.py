@@ -271,3 +271,69 @@ class KVCache:
 
     def device(self):
         return self._device
+
+
+class BatchMetadata:
+    """Flat per-step arrays for the batched kernels (SURVEY 8f-1; C++ nvllm::core::BatchMetadata):
+    what the reference's scheduler hands over one sequence at a time
+    (src/scheduler/batch.rs:227-375 -> paged.rs:117-192) flattened into block_tables,
+    context_lens, slot_mapping (block.rs:269-283 arithmetic) and query_start."""
+
+    def __init__(self, max_blocks_per_seq):
+        self._h = capi.lib().nvllm_batch_new(max_blocks_per_seq)
+        if not self._h:
+            raise ConfigError(capi.NVLLM_ERR_CONFIG)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            capi.lib().nvllm_batch_free(h)
+
+    def clear(self):
+        capi.lib().nvllm_batch_clear(self._h)
+
+    def add_sequence(self, table, context_len, num_new_tokens):
+        check(capi.lib().nvllm_batch_add_sequence(self._h, table.handle, context_len, num_new_tokens))
+
+    def num_seqs(self):
+        return int(capi.lib().nvllm_batch_num_seqs(self._h))
+
+    def num_tokens(self):
+        return int(capi.lib().nvllm_batch_num_tokens(self._h))
+
+    def max_blocks_per_seq(self):
+        return int(capi.lib().nvllm_batch_max_blocks_per_seq(self._h))
+
+    def _view(self, fn, ctype, n, dtype):
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        ptr = ctypes.cast(fn(self._h), ctypes.POINTER(ctype))
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def block_tables(self):
+        n = self.num_seqs()
+        return self._view(capi.lib().nvllm_batch_block_tables, ctypes.c_int32,
+                          n * self.max_blocks_per_seq(), np.int32).reshape(n, self.max_blocks_per_seq())
+
+    def context_lens(self):
+        return self._view(capi.lib().nvllm_batch_context_lens, ctypes.c_int32, self.num_seqs(), np.int32)
+
+    def slot_mapping(self):
+        return self._view(capi.lib().nvllm_batch_slot_mapping, ctypes.c_int64, self.num_tokens(), np.int64)
+
+    def query_start(self):
+        return self._view(capi.lib().nvllm_batch_query_start, ctypes.c_int32, self.num_seqs() + 1, np.int32)
+
+    def upload(self, device, stream=None):
+        """Device copies (block_tables, context_lens, slot_mapping, query_start) as torch tensors."""
+        import torch
+        n, t, mb = self.num_seqs(), self.num_tokens(), self.max_blocks_per_seq()
+        bt = torch.empty((n, mb), dtype=torch.int32, device=device)
+        cl = torch.empty((n,), dtype=torch.int32, device=device)
+        sm = torch.empty((t,), dtype=torch.int64, device=device)
+        qs = torch.empty((n + 1,), dtype=torch.int32, device=device)
+        st = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
+        check(capi.lib().nvllm_batch_upload(self._h, bt.data_ptr(), cl.data_ptr(), sm.data_ptr(),
+                                            qs.data_ptr(), st))
+        return bt, cl, sm, qs
+

@@ -23,6 +23,10 @@ struct nvllm_block_table {
     core::BlockTable table;
     explicit nvllm_block_table(std::size_t bs) : table(bs) {}
 };
+struct nvllm_batch {
+    core::BatchMetadata meta;
+    explicit nvllm_batch(std::size_t mb) : meta(mb) {}
+};
 struct nvllm_block_manager {
     core::BlockManager mgr;
     nvllm_block_manager(std::size_t n, std::size_t bs) : mgr(n, bs) {}
@@ -257,6 +261,50 @@ int64_t nvllm_block_table_get_slot_mapping(const nvllm_block_table *t, int64_t s
     const auto slots = t->table.get_slot_mapping((std::size_t)seq_len);
     for (int64_t i = 0; i < cap && i < (int64_t)slots.size(); ++i) slots_out[i] = (int64_t)slots[i];
     return (int64_t)slots.size();
+}
+
+nvllm_batch *nvllm_batch_new(int64_t max_blocks_per_seq) {
+    if (max_blocks_per_seq <= 0) {
+        set_last_error(ErrorKind::Config, "batch: max_blocks_per_seq must be positive");
+        return nullptr;
+    }
+    return new (std::nothrow) nvllm_batch((std::size_t)max_blocks_per_seq);
+}
+void nvllm_batch_free(nvllm_batch *b) { delete b; }
+void nvllm_batch_clear(nvllm_batch *b) { b->meta.clear(); }
+int nvllm_batch_add_sequence(nvllm_batch *b, const nvllm_block_table *t, int64_t context_len,
+                             int64_t num_new_tokens) {
+    if (!b || !t) return fail(ErrorKind::Null, "batch: null handle");
+    if (context_len < 0 || num_new_tokens < 0) return fail(ErrorKind::Config, "batch: negative length");
+    const nvllm::Error e = b->meta.add_sequence(t->table, (std::size_t)context_len, (std::size_t)num_new_tokens);
+    if (!e.ok()) return fail(e.kind, e.message);
+    return NVLLM_OK;
+}
+int64_t nvllm_batch_num_seqs(const nvllm_batch *b) { return (int64_t)b->meta.num_seqs(); }
+int64_t nvllm_batch_num_tokens(const nvllm_batch *b) { return (int64_t)b->meta.num_tokens(); }
+int64_t nvllm_batch_max_blocks_per_seq(const nvllm_batch *b) {
+    return (int64_t)b->meta.max_blocks_per_seq();
+}
+const int32_t *nvllm_batch_block_tables(const nvllm_batch *b) { return b->meta.block_tables().data(); }
+const int32_t *nvllm_batch_context_lens(const nvllm_batch *b) { return b->meta.context_lens().data(); }
+const int64_t *nvllm_batch_slot_mapping(const nvllm_batch *b) { return b->meta.slot_mapping().data(); }
+const int32_t *nvllm_batch_query_start(const nvllm_batch *b) { return b->meta.query_start().data(); }
+int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_context_lens,
+                       void *d_slot_mapping, void *d_query_start, nvllm_stream_t stream) {
+    if (!b) return fail(ErrorKind::Null, "batch: null handle");
+    const auto &m = b->meta;
+    hipStream_t st = as_stream(stream);
+    hipError_t err = hipSuccess;
+    auto copy = [&](void *dst, const void *src, size_t bytes) {
+        if (err == hipSuccess && dst && bytes) err = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    copy(d_block_tables, m.block_tables().data(), m.block_tables().size() * sizeof(int32_t));
+    copy(d_context_lens, m.context_lens().data(), m.context_lens().size() * sizeof(int32_t));
+    copy(d_slot_mapping, m.slot_mapping().data(), m.slot_mapping().size() * sizeof(int64_t));
+    copy(d_query_start, m.query_start().data(), m.query_start().size() * sizeof(int32_t));
+    if (err == hipSuccess) err = hipStreamSynchronize(st);  // the host arrays are pageable
+    if (err != hipSuccess) return hip_status(err, "batch upload");
+    return NVLLM_OK;
 }
 
 nvllm_block_manager *nvllm_block_manager_new(int64_t num_blocks, int64_t block_size) {

@@ -243,5 +243,39 @@ std::int64_t slot_mapping_last_writer(const std::int64_t *slots, std::int64_t n,
     return superseded;
 }
 
+void BatchMetadata::clear() {
+    block_tables_.clear();
+    context_lens_.clear();
+    slot_mapping_.clear();
+    query_start_.assign(1, 0);
+}
+
+Error BatchMetadata::add_sequence(const BlockTable &table, std::size_t context_len,
+                                  std::size_t num_new_tokens) {
+    const std::size_t bs = table.block_size();
+    const auto &ids = table.get_physical_block_ids();
+    if (num_new_tokens > context_len)
+        return Error{ErrorKind::Config, "batch: " + std::to_string(num_new_tokens) +
+                                            " new tokens exceed context_len " +
+                                            std::to_string(context_len)};
+    if (context_len > ids.size() * bs)
+        return Error{ErrorKind::Config, "batch: context_len " + std::to_string(context_len) +
+                                            " exceeds the " + std::to_string(ids.size()) +
+                                            " allocated blocks"};
+    if (ids.size() > max_blocks_)
+        return Error{ErrorKind::Config, "batch: block table longer than max_blocks_per_seq"};
+    if (context_len > 0x7fffffffu) return Error{ErrorKind::Config, "batch: context_len too large"};
+    for (std::size_t i = 0; i < max_blocks_; ++i) {
+        const std::size_t id = i < ids.size() ? ids[i] : 0;
+        if (id > 0x7fffffffu) return Error{ErrorKind::Config, "batch: block id exceeds int32"};
+        block_tables_.push_back(static_cast<std::int32_t>(id));
+    }
+    context_lens_.push_back(static_cast<std::int32_t>(context_len));
+    for (std::size_t p = context_len - num_new_tokens; p < context_len; ++p)  // block.rs:272-279
+        slot_mapping_.push_back(static_cast<std::int64_t>(ids[p / bs] * bs + p % bs));
+    query_start_.push_back(static_cast<std::int32_t>(slot_mapping_.size()));
+    return Error{};
+}
+
 }  // namespace core
 }  // namespace nvllm

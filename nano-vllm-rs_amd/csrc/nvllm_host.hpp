@@ -101,6 +101,39 @@ class BlockTable {
     std::size_t block_size_;
 };
 
+// Batched step metadata.  The reference's scheduler hands out sequences one at a
+// time (src/scheduler/batch.rs:227-375) and paged_attention takes one BlockTable per call
+// (src/attention/paged.rs:117-192).  The batched kernels take flat arrays instead; this builder
+// turns the scheduled sequences of one step into them, with the reference's own slot arithmetic
+// (block.rs:269-283) for the tokens whose K/V are written this step:
+//   block_tables  int32 [num_seqs, max_blocks_per_seq]   (row padded with 0)
+//   context_lens  int32 [num_seqs]                        (context INCLUDING the new tokens)
+//   slot_mapping  int64 [num_tokens]                      (new tokens of all sequences, in order)
+//   query_start   int32 [num_seqs + 1]                    (first new-token row of each sequence)
+class BatchMetadata {
+  public:
+    explicit BatchMetadata(std::size_t max_blocks_per_seq) : max_blocks_(max_blocks_per_seq) {
+        query_start_.push_back(0);
+    }
+    void clear();
+    // context_len tokens are in the cache after this step, the last num_new_tokens of them are
+    // new.  Errors (Config): more new tokens than context, context beyond the table's blocks
+    // (the reference's narrow() fails there, paged.rs:150), table longer than max_blocks_per_seq.
+    Error add_sequence(const BlockTable &table, std::size_t context_len, std::size_t num_new_tokens);
+    std::size_t max_blocks_per_seq() const { return max_blocks_; }
+    std::size_t num_seqs() const { return context_lens_.size(); }
+    std::size_t num_tokens() const { return slot_mapping_.size(); }
+    const std::vector<std::int32_t> &block_tables() const { return block_tables_; }
+    const std::vector<std::int32_t> &context_lens() const { return context_lens_; }
+    const std::vector<std::int64_t> &slot_mapping() const { return slot_mapping_; }
+    const std::vector<std::int32_t> &query_start() const { return query_start_; }
+
+  private:
+    std::size_t max_blocks_;
+    std::vector<std::int32_t> block_tables_, context_lens_, query_start_;
+    std::vector<std::int64_t> slot_mapping_;
+};
+
 // block_manager.rs:40-383
 class BlockManager {
   public:
