@@ -57,6 +57,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// indexed ("idxen") buffer load: address = base + index * stride; hipcc has no builtin for it
+__device__ i32x4 struct_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset,
+                                         int soffset, int aux)
+    __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
 
 constexpr int kD = 128;
 constexpr int kWaves = 4;
@@ -216,11 +221,19 @@ __device__ __forceinline__ void pin(float &x, float &y, u32x4 &z) {
 }
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
-template <bool CAUSAL>
+// PAGED = K/V come from the paged cache ([num_blocks, 16, Hkv, 128], k / v = cache bases) through
+// this sequence's block table, Skv is the sequence's context length and the causal mask is
+// bottom-right aligned: query row i sits at position Skv - Sq + i (paged.rs:357-381).  The kernel
+// then tiles the query POSITIONS, from the largest multiple of 32 below the first one, so that a
+// 32-row block's diagonal stays inside one 64-key tile exactly as in the top-left case.
+template <bool CAUSAL, bool PAGED>
 __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
     __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv, int Hq, int Hkv,
-    int num_q_tiles, int pair_adjacent, float scale_log2e) {
+    int num_q_tiles, int pair_adjacent, float scale_log2e,
+    const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
+    int max_blocks_per_seq, unsigned num_cache_chunks) {
+    static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
 
     const int tid = threadIdx.x;
@@ -238,6 +251,19 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const int J = bid / G;
     const int hq = kvh * G + hg;
     const int b = blockIdx.y;
+    // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
+    // the tiling starts) and the dead rows in front of the first block (pos_shift)
+    int kv_off = 0, pos_base = 0, pos_shift = 0;
+    if constexpr (PAGED) {
+        Skv = context_lens[b];
+        const int cap = max_blocks_per_seq * 16;
+        Skv = Skv < 0 ? 0 : (Skv > cap ? cap : Skv);
+        kv_off = Skv - Sq;
+        pos_shift = kv_off & 31;
+        pos_base = kv_off - pos_shift;
+        num_q_tiles = (Sq + pos_shift + kQTile - 1) / kQTile;
+        if (J >= (num_q_tiles + 1) / 2) return;  // the grid is sized for pos_shift = 31
+    }
     // Which two query tiles this workgroup owns.  Balanced pairing (J, NT-1-J) gives every
     // workgroup the same causal work -- the choice when the grid is about one workgroup per CU.
     // Adjacent pairing (2J, 2J+1), heaviest pairs first, keeps both blocks on the same key
@@ -252,11 +278,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     }
 
     const int nkv = (Skv + kKV - 1) / kKV;
+    // r0 = first row of a block, counted from pos_base - kv_off (= row 0 unless PAGED)
     auto tiles_for = [&](int r0) {
-        if (r0 >= Sq) return 0;
+        if (r0 - pos_shift >= Sq) return 0;
         int n = nkv;
         if (CAUSAL) {
-            const int d = (r0 + 31) / kKV + 1;
+            const int last = r0 + 31 + pos_base;  // last position of the block
+            if (last < 0) return 0;
+            const int d = last / kKV + 1;
             n = d < n ? d : n;
         }
         return n;
@@ -272,23 +301,27 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // key tiles the workgroup walks (same in every wave)
     int nsteps = nkv;
     if (CAUSAL) {
-        int last = tile_long * kQTile + kQTile - 1;
-        last = last < Sq - 1 ? last : Sq - 1;
-        const int d = last / kKV + 1;
+        int last = tile_long * kQTile + kQTile - 1 + pos_base;
+        last = last < Sq - 1 + kv_off ? last : Sq - 1 + kv_off;
+        const int d = last < 0 ? 0 : last / kKV + 1;
         nsteps = d < nsteps ? d : nsteps;
     }
+    // a block with rows to store may have no keys at all (PAGED, context shorter than the chunk)
+    const bool liveA = rowA0 - pos_shift < Sq;
+    const bool liveB = tile_short != tile_long && rowB0 - pos_shift < Sq;
 
-    Block A, B;
-    A.qrow = rowA0 + c;
-    B.qrow = rowB0 + c;
+    Block A, B;  // qrow = the lane's query POSITION (= row unless PAGED)
+    A.qrow = rowA0 + pos_base + c;
+    B.qrow = rowB0 + pos_base + c;
     // reserves a[0:223] in the kernel descriptor; every later statement names them literally
     asm volatile("" ::: K1_AGPRS);
     constexpr ic<0> kA{};
     constexpr ic<1> kB{};
     auto load_q = [&](Block &blk, auto bt, bool live) {
         constexpr int bi = decltype(bt)::value;
-        const bool ok = live && blk.qrow < Sq;
-        const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? blk.qrow : 0)) * Hq + hq) * kD + 8 * h;
+        const int row = blk.qrow - kv_off;
+        const bool ok = live && row >= 0 && row < Sq;
+        const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? row : 0)) * Hq + hq) * kD + 8 * h;
         u32x4 x[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -303,8 +336,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         static_for<16>([&](auto R) { agpr_write<192 + 16 * bi + decltype(R)::value>(0u); });
         blk.m = -INFINITY;
     };
-    load_q(A, kA, nA > 0);
-    load_q(B, kB, nB > 0);
+    load_q(A, kA, liveA);
+    load_q(B, kB, liveB);
 
     // ---- staging: thread handles rows st_row0 + 16i (i = 0..3), 16-byte chunk st_ch, of the K and
     // of the V tile: 8 pieces per tile and thread (0..3 = K rows, 4..7 = V rows).  Buffer loads
@@ -314,21 +347,55 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const int st_ch = tid & 15;
     const int st_row0 = tid >> 4;
     const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
-    const unsigned kv_bytes = (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
-    const int64_t head_off = ((int64_t)b * Skv * Hkv + kvh) * kD;
-    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(k + head_off), 0,
-                                                          (int)kv_bytes, 0x00020000);
-    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(v + head_off), 0,
-                                                          (int)kv_bytes, 0x00020000);
+    const unsigned kv_bytes = PAGED ? 0u : (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
+    const int64_t head_off = PAGED ? 0 : ((int64_t)b * Skv * Hkv + kvh) * kD;
+    // PAGED: the caches are addressed as arrays of 16-byte chunks (stride 16, indexed loads): a
+    // 32-bit chunk index reaches 64 GiB, and an index past the cache reads as zero like above.
+    // Piece i of key tile t is the 16 rows of the sequence's block 4t + i, whose id comes from the
+    // block table (a raw buffer over this sequence's row: entries past it read as id 0).  Rows
+    // past the context (never written, or stale) are given the index -1: their V must be a true
+    // zero, P = 0 would not silence a NaN.
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(k + head_off), PAGED ? 16 : 0, PAGED ? (int)num_cache_chunks : (int)kv_bytes,
+        0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(v + head_off), PAGED ? 16 : 0, PAGED ? (int)num_cache_chunks : (int)kv_bytes,
+        0x00020000);
+    const auto tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>(PAGED ? block_tables + (int64_t)b * max_blocks_per_seq : nullptr), 0,
+        PAGED ? max_blocks_per_seq * 4 : 0, 0x00020000);
+    const unsigned pg_chunks_per_block = (unsigned)(16 * Hkv * 16);
+    const unsigned pg_chunk0 = (unsigned)((st_row0 * Hkv + kvh) * 16 + st_ch);
+    const int pg_blk_lim = (Skv - st_row0 + 15) >> 4;  // blocks holding a row st_row0 below Skv
     const unsigned st_voff = (unsigned)st_row0 * row_bytes + 16u * (unsigned)st_ch;
     const unsigned st_kw = (unsigned)(kKBase + st_row0 * kKRow + 16 * st_ch);
     const unsigned st_vw = (unsigned)(st_row0 * kVRow + 16 * (st_ch ^ (4 * (st_row0 & 3))));
     u32x4 st[8];
+    unsigned pg_id[4], pg_idx[4];
+    // PAGED: fetch the four block ids of key tile t (early in a step; stage_l uses them later)
+    auto stage_ids = [&](int t) {
+        if constexpr (PAGED) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                pg_id[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * t, 0);
+        }
+    };
     // fetch piece j of key tile t
     auto stage_l = [&](int t, int j) {
-        const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
-        st[j] = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc, st_voff, soff, 0));
+        if constexpr (PAGED) {
+            if (j < 4) {
+                unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
+                asm("v_mad_u32_u24 %0, %1, %2, %3"
+                    : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
+                pg_idx[j] = (4 * t + j >= pg_blk_lim) ? 0xffffffffu : idx;
+            }
+            st[j] = __builtin_bit_cast(u32x4, struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
+                                                                      (int)pg_idx[j & 3], 0, 0, 0));
+        } else {
+            const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
+            st[j] = __builtin_bit_cast(
+                u32x4, __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc, st_voff, soff, 0));
+        }
     };
     // write piece j to K ring slot kslot / V ring slot vslot
     auto stage_w = [&](int kslot, int vslot, int j) {
@@ -338,6 +405,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = st[j];
     };
     auto stage_load = [&](int t) {
+        stage_ids(t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_l(t, j);
     };
@@ -733,6 +801,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     };
     // block A alone, interior tile: QK^T into `nxt` while `cur` (pending) is finished and multiplied
     auto single_step = [&](Item &cur, Item &nxt) {
+        stage_ids(t + 2);
         prime_k();
         slot_qk(nxt, kA, ks_cur, cur, [&](int i) { valu_qk(cur, i); st_w8(i); },
                 [&](int j) { read_v(vs_prev, j); });
@@ -756,6 +825,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // both blocks, interior tile: QK^T of tile t into (nA_, nB_) while the pending items (pA, pB:
     // tile t-1) are finished and multiplied
     auto dual_step = [&](Item &pA, Item &pB, Item &nA_, Item &nB_) {
+        stage_ids(t + 2);
         prime_k();
         slot_qk2(nA_, nB_, ks_cur, pA, pB,
                  [&](int k) {
@@ -847,9 +917,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             constexpr int r = decltype(R)::value;
             ov[r] = agpr_read<64 * bi + r>();
         });
-        if (live && blk.qrow < Sq) {
+        const int row = blk.qrow - kv_off;
+        if (live && row >= 0 && row < Sq) {
             const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-            __bf16 *op = o + (((int64_t)b * Sq + blk.qrow) * Hq + hq) * kD + 4 * h;
+            __bf16 *op = o + (((int64_t)b * Sq + row) * Hq + hq) * kD + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -861,14 +932,28 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
                 }
             if (lse && h == 0)
-                lse[((int64_t)b * Hq + hq) * Sq + blk.qrow] =
+                lse[((int64_t)b * Hq + hq) * Sq + row] =
                     blk.m * scale_log2e * 0.6931471805599453f + logf(l);
         }
     };
-    store(A, kA, nA > 0);
-    store(B, kB, nB > 0);
+    store(A, kA, liveA);
+    store(B, kB, liveB);
 }
 
+}  // namespace
+
+namespace {
+int device_cus() {
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        num_cus = n;
+    }
+    return num_cus;
+}
 }  // namespace
 
 bool flash_attn_mfma_supported(const FlashAttnArgs &a) {
@@ -885,15 +970,7 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     const int num_q_tiles = (a.seq_q + kQTile - 1) / kQTile;
     const int pairs = (num_q_tiles + 1) / 2;
     // adjacent pairing once there are at least two workgroups per CU (MI355X: 256 CUs)
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        num_cus = n;
-    }
-    int pair_adjacent = (int64_t)pairs * a.num_heads * a.batch >= (int64_t)2 * num_cus;
+    int pair_adjacent = (int64_t)pairs * a.num_heads * a.batch >= (int64_t)2 * device_cus();
     if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
     const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.batch), block(64 * kWaves);
     const float scale_log2e = a.softmax_scale * 1.4426950408889634f;
@@ -902,13 +979,47 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     auto v = static_cast<const __bf16 *>(a.v);
     auto o = static_cast<__bf16 *>(a.o);
     if (a.causal)
-        flash_attn_mfma_kernel<true><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<true, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u);
     else
-        flash_attn_mfma_kernel<false><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u);
+    return hipGetLastError();
+}
+
+// Chunked prefill / speculative verify over the paged cache: T new tokens per sequence against
+// context_lens[seq] cached keys (the new tokens' K/V already written), more query rows per kv head
+// than the decode kernel's 32 (paged_attn.hip).  Same contract as launch_paged_attn.
+bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a) {
+    if (dt != DType::BF16 || a.head_dim != kD || a.block_size != 16) return false;
+    if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
+    if (a.num_seqs <= 0 || a.num_seqs > 65535 || a.num_new_tokens <= 0) return false;
+    if (a.max_blocks_per_seq <= 0 || a.max_blocks_per_seq > (1 << 26)) return false;
+    // 32-bit index of 16-byte chunks over one cache, block ids in 24 bits
+    const int64_t chunks = a.num_cache_blocks * 16 * a.num_kv_heads * 16;
+    if (a.num_cache_blocks <= 0 || a.num_cache_blocks >= (1 << 24) || chunks >= ((int64_t)1 << 32) ||
+        16 * a.num_kv_heads * 16 >= (1 << 24))
+        return false;
+    const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    return al(a.q) && al(a.k_cache) && al(a.v_cache) && al(a.out);
+}
+
+hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
+    // query positions are tiled from a multiple of 32: up to 31 dead rows in front of a sequence
+    const int num_q_tiles = (a.num_new_tokens + 31 + kQTile - 1) / kQTile;
+    const int pairs = (num_q_tiles + 1) / 2;
+    int pair_adjacent = (int64_t)pairs * a.num_heads * a.num_seqs >= (int64_t)2 * device_cus();
+    if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
+    const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs), block(64 * kWaves);
+    const float scale_log2e = a.scale * 1.4426950408889634f;
+    const unsigned chunks = (unsigned)(a.num_cache_blocks * 16 * a.num_kv_heads * 16);
+    flash_attn_mfma_kernel<true, true><<<grid, block, 0, stream>>>(
+        static_cast<const __bf16 *>(a.q), static_cast<const __bf16 *>(a.k_cache),
+        static_cast<const __bf16 *>(a.v_cache), static_cast<__bf16 *>(a.out), nullptr,
+        a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles, pair_adjacent, scale_log2e,
+        a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks);
     return hipGetLastError();
 }
 

@@ -630,6 +630,10 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         }
         return err;
     }
+    // more than 32 query rows per kv head (chunked prefill, long verify): the prefill kernel
+    // reading K/V through the block table
+    if (env_int("NVLLM_PAGED_FLASH", 1) != 0 && flash_attn_paged_supported(dt, a))
+        return launch_flash_attn_paged(a, stream);
     // generic
     const dim3 grid(a.num_heads, a.num_new_tokens, a.num_seqs), block(64);
     if (dt == DType::BF16)
