@@ -92,8 +92,11 @@ int nvllm_flash_attn_fwd_f32(const void *q, const void *k, const void *v, void *
  * the last block are never read into the result (they may hold anything).
  * `workspace` is split-K scratch of at least nvllm_paged_attn_workspace_bytes()
  * bytes (may be NULL when that returns 0).
- * bf16: head_dim 128, block_size 16, num_new_tokens * (num_heads/num_kv_heads)
- * <= 32 run the MFMA/bandwidth kernel; other shapes run the generic kernel. */
+ * bf16, head_dim 128, block_size 16: num_new_tokens * (num_heads/num_kv_heads)
+ * <= 32 runs the bandwidth kernel (decode, short verify); more query rows
+ * (chunked prefill, long verify) run the prefill kernel reading K/V through the
+ * block table (needs a cache of < 64 GiB and < 2^24 blocks); other shapes run
+ * the generic kernel. */
 int nvllm_paged_attn_bf16(const void *q, const void *k_cache, const void *v_cache,
                           const int32_t *block_tables, const int32_t *context_lens, void *out,
                           void *workspace, size_t workspace_bytes, int num_seqs,
