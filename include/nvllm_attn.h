@@ -138,6 +138,42 @@ int nvllm_reshape_and_cache_f32(const void *key, const void *value, void *k_cach
                                 int head_dim, int block_size, int64_t num_cache_blocks,
                                 nvllm_stream_t stream);
 
+/* Producer side of the paged cache in one pass: per-head RMSNorm of Q and K, RoPE, then K (rotated)
+ * and V go into their cache slots -- no intermediate tensors.
+ * Replaces: steps 3-5 of Qwen3Attention::forward (src/model/attention.rs:229-254):
+ *   apply_head_norm = RmsNorm::forward over head_dim (src/model/norm.rs:83-100):
+ *       x / sqrt(mean(x^2) + eps) * weight
+ *   RotaryEmbedding::apply (src/model/rope.rs:107-152):
+ *       x * cos[pos] + cat(-x[D/2:], x[:D/2]) * sin[pos]
+ *   the cache append (there Tensor::cat; here the slot write of nvllm_reshape_and_cache_*).
+ *   q [num_tokens, num_heads, head_dim] -> q_out (same shape; may be q itself)
+ *   k, v [num_tokens, num_kv_heads, head_dim]; k_out optional (NULL, or [num_tokens,
+ *       num_kv_heads, head_dim]: the rotated K, contiguous, for a dense prefill)
+ *   q_weight, k_weight [head_dim]  (q_norm / k_norm weights, attention.rs:165-166)
+ *   cos_cache, sin_cache [max_positions, head_dim] as RotaryEmbedding holds them
+ *       (rope.rs:20-23; nvllm_rope_cache_f32 builds them)
+ *   positions int32 [num_tokens]: each token's position in its sequence (start_pos + i);
+ *       the reference fails on a position past the tables (narrow, rope.rs:111) -- a device
+ *       array cannot be validated without a sync, so the kernel clamps into [0, max_positions)
+ *   slot_mapping as nvllm_reshape_and_cache_* (negative / out-of-pool slot: the cache write of
+ *       that token is skipped, q_out and k_out are still produced)
+ * All tensors in the entry's element type; arithmetic in f32, one rounding at the end. */
+int nvllm_qk_norm_rope_cache_bf16(const void *q, const void *k, const void *v, void *q_out,
+                                  void *k_out, const void *q_weight, const void *k_weight,
+                                  float eps, const void *cos_cache, const void *sin_cache,
+                                  int64_t max_positions, const int32_t *positions, void *k_cache,
+                                  void *v_cache, const int64_t *slot_mapping, int64_t num_tokens,
+                                  int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                  int64_t num_cache_blocks, nvllm_stream_t stream);
+
+int nvllm_qk_norm_rope_cache_f32(const void *q, const void *k, const void *v, void *q_out,
+                                 void *k_out, const void *q_weight, const void *k_weight, float eps,
+                                 const void *cos_cache, const void *sin_cache,
+                                 int64_t max_positions, const int32_t *positions, void *k_cache,
+                                 void *v_cache, const int64_t *slot_mapping, int64_t num_tokens,
+                                 int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                 int64_t num_cache_blocks, nvllm_stream_t stream);
+
 /* Replaces: flash_attention_get_last_error (kernels/flash_attn_fwd.cu:540-543).
  * Thread-local; never NULL. */
 const char *nvllm_get_last_error(void);
@@ -160,6 +196,12 @@ int64_t nvllm_compute_num_blocks(int64_t seq_len, int64_t block_size);
  * [parent_hash as u64 LE, if has_parent] ++ tokens as u32 LE. */
 uint64_t nvllm_hash_token_block(const uint32_t *token_ids, int64_t num_tokens, int has_parent,
                                 uint64_t parent_hash);
+
+/* RotaryEmbedding::new (src/model/rope.rs:42-80), host side: cos / sin tables
+ * [max_seq_len, dim] in f32 (inv_freq in f64 -> f32, angle = pos * inv_freq in f32, the row is
+ * the half-row twice).  Odd dim -> NVLLM_ERR_CONFIG (the reference panics). */
+int nvllm_rope_cache_f32(int64_t dim, int64_t max_seq_len, double theta, float *cos_out,
+                         float *sin_out);
 
 /* Host-side helper for nvllm_reshape_and_cache_*: copies `slots` to `out`,
  * replacing every entry that a LATER entry overwrites by -1, so a parallel
@@ -252,10 +294,13 @@ const int32_t *nvllm_batch_block_tables(const nvllm_batch *b);
 const int32_t *nvllm_batch_context_lens(const nvllm_batch *b);
 const int64_t *nvllm_batch_slot_mapping(const nvllm_batch *b);
 const int32_t *nvllm_batch_query_start(const nvllm_batch *b);
+/* int32 [num_tokens]: each new token's position in its sequence (the RoPE row) */
+const int32_t *nvllm_batch_positions(const nvllm_batch *b);
 /* any destination may be NULL (skipped); the copies are issued on `stream` and complete before
  * the call returns (the host arrays are pageable) */
 int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_context_lens,
-                       void *d_slot_mapping, void *d_query_start, nvllm_stream_t stream);
+                       void *d_slot_mapping, void *d_query_start, void *d_positions,
+                       nvllm_stream_t stream);
 
 /* paged_attention exactly as src/attention/paged.rs:117-126 takes it: one
  * sequence, a host BlockTable, the layer's cache.  Validates like the

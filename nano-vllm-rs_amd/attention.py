@@ -153,6 +153,54 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):
              Hkv, D, bs, nb, _stream()))
 
 
+class RotaryEmbedding:
+    """rope.rs:18-152 mirror: cos/sin tables [max_seq_len, dim] built on the host by
+    nvllm_rope_cache_f32 (the reference's arithmetic) and held on `device` in `dtype`."""
+
+    def __init__(self, dim, max_seq_len, theta, dtype, device):
+        cos = np.empty((max_seq_len, dim), dtype=np.float32)
+        sin = np.empty((max_seq_len, dim), dtype=np.float32)
+        check(capi.lib().nvllm_rope_cache_f32(dim, max_seq_len, float(theta), cos.ctypes.data,
+                                              sin.ctypes.data))
+        self._dim = dim
+        self._cos = torch.from_numpy(cos).to(device=device, dtype=dtype)
+        self._sin = torch.from_numpy(sin).to(device=device, dtype=dtype)
+
+    def dim(self):
+        return self._dim
+
+    def cos_cache(self):
+        return self._cos
+
+    def sin_cache(self):
+        return self._sin
+
+
+def qk_norm_rope_cache(query, key, value, q_weight, k_weight, eps, rotary, positions, key_cache,
+                       value_cache, slot_mapping, k_out=None, q_out=None):
+    """Steps 3-5 of Qwen3Attention::forward (attention.rs:229-254) fused: per-head RMSNorm of Q
+    and K, RoPE at `positions`, K and V into their cache slots.  query [num_tokens,Hq,D],
+    key/value [num_tokens,Hkv,D], positions int32 / slot_mapping int64 [num_tokens] on device.
+    Returns q_out (query itself unless q_out is given)."""
+    _require_device(query, key, value, q_weight, k_weight, positions, key_cache, value_cache,
+                    slot_mapping)
+    assert positions.dtype == torch.int32 and slot_mapping.dtype == torch.int64
+    n, Hq, D = query.shape
+    Hkv = key.shape[1]
+    nb, bs = key_cache.shape[0], key_cache.shape[1]
+    if q_out is None:
+        q_out = query
+    cos, sin = rotary.cos_cache(), rotary.sin_cache()
+    assert cos.dtype == query.dtype and cos.shape[1] == D
+    fn = (capi.lib().nvllm_qk_norm_rope_cache_bf16 if _dtype_code(query) == 0
+          else capi.lib().nvllm_qk_norm_rope_cache_f32)
+    check(fn(_ptr(query), _ptr(key), _ptr(value), _ptr(q_out),
+             _ptr(k_out) if k_out is not None else None, _ptr(q_weight), _ptr(k_weight), float(eps),
+             _ptr(cos), _ptr(sin), cos.shape[0], _ptr(positions), _ptr(key_cache),
+             _ptr(value_cache), _ptr(slot_mapping), n, Hq, Hkv, D, bs, nb, _stream()))
+    return q_out
+
+
 def write_kv_to_cache(key, value, key_cache, value_cache, slot_mapping, block_size):
     """paged.rs:208-215: key/value [1,S,Hkv,D], HOST slot mapping (list of ints).
     Updates the caches in place and returns them."""

@@ -15,6 +15,7 @@ SOURCES = [
     "nvllm_host.cpp",
     "capi.cpp",
     "reshape_and_cache.hip",
+    "qk_norm_rope_cache.hip",
     "paged_attn.hip",
     "flash_attn.hip",
     "flash_attn_mfma.hip",

@@ -33,6 +33,9 @@ SIGNATURES = {
     "nvllm_paged_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "nvllm_reshape_and_cache_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),
     "nvllm_reshape_and_cache_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),
+    "nvllm_qk_norm_rope_cache_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i64, _vp]),
+    "nvllm_qk_norm_rope_cache_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i64, _vp]),
+    "nvllm_rope_cache_f32": (_i, [_i64, _i64, _d, _vp, _vp]),
     "nvllm_get_last_error": (_c.c_char_p, []),
     "nvllm_synchronize": (_i, []),
     "nvllm_device_count": (_i, []),
@@ -61,7 +64,8 @@ SIGNATURES = {
     "nvllm_batch_context_lens": (_vp, [_vp]),
     "nvllm_batch_slot_mapping": (_vp, [_vp]),
     "nvllm_batch_query_start": (_vp, [_vp]),
-    "nvllm_batch_upload": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvllm_batch_positions": (_vp, [_vp]),
+    "nvllm_batch_upload": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nvllm_block_manager_new": (_vp, [_i64, _i64]),
     "nvllm_block_manager_free_handle": (None, [_vp]),
     "nvllm_block_manager_block_size": (_i64, [_vp]),

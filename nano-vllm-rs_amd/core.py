@@ -324,16 +324,21 @@ class BatchMetadata:
     def query_start(self):
         return self._view(capi.lib().nvllm_batch_query_start, ctypes.c_int32, self.num_seqs() + 1, np.int32)
 
+    def positions(self):
+        return self._view(capi.lib().nvllm_batch_positions, ctypes.c_int32, self.num_tokens(), np.int32)
+
     def upload(self, device, stream=None):
-        """Device copies (block_tables, context_lens, slot_mapping, query_start) as torch tensors."""
+        """Device copies (block_tables, context_lens, slot_mapping, query_start, positions) as
+        torch tensors."""
         import torch
         n, t, mb = self.num_seqs(), self.num_tokens(), self.max_blocks_per_seq()
         bt = torch.empty((n, mb), dtype=torch.int32, device=device)
         cl = torch.empty((n,), dtype=torch.int32, device=device)
         sm = torch.empty((t,), dtype=torch.int64, device=device)
         qs = torch.empty((n + 1,), dtype=torch.int32, device=device)
+        ps = torch.empty((t,), dtype=torch.int32, device=device)
         st = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
         check(capi.lib().nvllm_batch_upload(self._h, bt.data_ptr(), cl.data_ptr(), sm.data_ptr(),
-                                            qs.data_ptr(), st))
-        return bt, cl, sm, qs
+                                            qs.data_ptr(), ps.data_ptr(), st))
+        return bt, cl, sm, qs, ps
 

@@ -114,6 +114,30 @@ int reshape_common(int elt, const void *key, const void *value, void *k_cache, v
                       "reshape_and_cache launch");
 }
 
+int qk_norm_rope_common(kernels::DType dt, const void *q, const void *k, const void *v, void *q_out,
+                        void *k_out, const void *q_weight, const void *k_weight, float eps,
+                        const void *cos_cache, const void *sin_cache, int64_t max_positions,
+                        const int32_t *positions, void *k_cache, void *v_cache,
+                        const int64_t *slot_mapping, int64_t num_tokens, int num_heads,
+                        int num_kv_heads, int head_dim, int block_size, int64_t num_cache_blocks,
+                        nvllm_stream_t stream) {
+    if (num_tokens < 0 || num_heads <= 0 || num_kv_heads <= 0 || head_dim <= 0 || block_size <= 0 ||
+        num_cache_blocks <= 0 || max_positions <= 0 || max_positions > 0x7fffffff)
+        return fail(ErrorKind::Config, "qk_norm_rope_cache: negative or zero dimension");
+    if (head_dim % 2 != 0)  // rope.rs:49 assert!(dim.is_multiple_of(2))
+        return fail(ErrorKind::Config, "qk_norm_rope_cache: RoPE dimension must be even");
+    if (num_tokens == 0) return NVLLM_OK;
+    if (!q || !k || !v || !q_out || !q_weight || !k_weight || !cos_cache || !sin_cache ||
+        !positions || !k_cache || !v_cache || !slot_mapping)
+        return fail(ErrorKind::Null, "qk_norm_rope_cache: null pointer");
+    kernels::QkNormRopeCacheArgs a{q, k, v, q_out, k_out, q_weight, k_weight, eps, cos_cache,
+                                   sin_cache, (int)max_positions, positions, k_cache, v_cache,
+                                   slot_mapping, num_tokens, num_heads, num_kv_heads, head_dim,
+                                   block_size, num_cache_blocks};
+    return hip_status(kernels::launch_qk_norm_rope_cache(dt, a, as_stream(stream)),
+                      "qk_norm_rope_cache launch");
+}
+
 }  // namespace
 
 extern "C" {
@@ -208,6 +232,41 @@ int64_t nvllm_compute_num_blocks(int64_t seq_len, int64_t block_size) {
     return (int64_t)core::compute_num_blocks((std::size_t)seq_len, (std::size_t)block_size);
 }
 
+int nvllm_qk_norm_rope_cache_bf16(const void *q, const void *k, const void *v, void *q_out,
+                                  void *k_out, const void *q_weight, const void *k_weight,
+                                  float eps, const void *cos_cache, const void *sin_cache,
+                                  int64_t max_positions, const int32_t *positions, void *k_cache,
+                                  void *v_cache, const int64_t *slot_mapping, int64_t num_tokens,
+                                  int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                  int64_t num_cache_blocks, nvllm_stream_t stream) {
+    return qk_norm_rope_common(kernels::DType::BF16, q, k, v, q_out, k_out, q_weight, k_weight, eps,
+                               cos_cache, sin_cache, max_positions, positions, k_cache, v_cache,
+                               slot_mapping, num_tokens, num_heads, num_kv_heads, head_dim,
+                               block_size, num_cache_blocks, stream);
+}
+
+int nvllm_qk_norm_rope_cache_f32(const void *q, const void *k, const void *v, void *q_out,
+                                 void *k_out, const void *q_weight, const void *k_weight, float eps,
+                                 const void *cos_cache, const void *sin_cache,
+                                 int64_t max_positions, const int32_t *positions, void *k_cache,
+                                 void *v_cache, const int64_t *slot_mapping, int64_t num_tokens,
+                                 int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                 int64_t num_cache_blocks, nvllm_stream_t stream) {
+    return qk_norm_rope_common(kernels::DType::F32, q, k, v, q_out, k_out, q_weight, k_weight, eps,
+                               cos_cache, sin_cache, max_positions, positions, k_cache, v_cache,
+                               slot_mapping, num_tokens, num_heads, num_kv_heads, head_dim,
+                               block_size, num_cache_blocks, stream);
+}
+
+int nvllm_rope_cache_f32(int64_t dim, int64_t max_seq_len, double theta, float *cos_out,
+                         float *sin_out) {
+    if (dim <= 0 || max_seq_len < 0) return fail(ErrorKind::Config, "rope_cache: bad dimension");
+    if (dim % 2 != 0) return fail(ErrorKind::Config, "RoPE dimension must be even");
+    if (!cos_out || !sin_out) return fail(ErrorKind::Null, "rope_cache: null pointer");
+    core::rope_cache((std::size_t)dim, (std::size_t)max_seq_len, theta, cos_out, sin_out);
+    return NVLLM_OK;
+}
+
 uint64_t nvllm_hash_token_block(const uint32_t *token_ids, int64_t num_tokens, int has_parent,
                                 uint64_t parent_hash) {
     return core::hash_token_block(token_ids, num_tokens > 0 ? (std::size_t)num_tokens : 0,
@@ -289,8 +348,10 @@ const int32_t *nvllm_batch_block_tables(const nvllm_batch *b) { return b->meta.b
 const int32_t *nvllm_batch_context_lens(const nvllm_batch *b) { return b->meta.context_lens().data(); }
 const int64_t *nvllm_batch_slot_mapping(const nvllm_batch *b) { return b->meta.slot_mapping().data(); }
 const int32_t *nvllm_batch_query_start(const nvllm_batch *b) { return b->meta.query_start().data(); }
+const int32_t *nvllm_batch_positions(const nvllm_batch *b) { return b->meta.positions().data(); }
 int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_context_lens,
-                       void *d_slot_mapping, void *d_query_start, nvllm_stream_t stream) {
+                       void *d_slot_mapping, void *d_query_start, void *d_positions,
+                       nvllm_stream_t stream) {
     if (!b) return fail(ErrorKind::Null, "batch: null handle");
     const auto &m = b->meta;
     hipStream_t st = as_stream(stream);
@@ -302,6 +363,7 @@ int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_conte
     copy(d_context_lens, m.context_lens().data(), m.context_lens().size() * sizeof(int32_t));
     copy(d_slot_mapping, m.slot_mapping().data(), m.slot_mapping().size() * sizeof(int64_t));
     copy(d_query_start, m.query_start().data(), m.query_start().size() * sizeof(int32_t));
+    copy(d_positions, m.positions().data(), m.positions().size() * sizeof(int32_t));
     if (err == hipSuccess) err = hipStreamSynchronize(st);  // the host arrays are pageable
     if (err != hipSuccess) return hip_status(err, "batch upload");
     return NVLLM_OK;

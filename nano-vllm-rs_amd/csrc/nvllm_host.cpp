@@ -1,6 +1,8 @@
 // nvllm_host.cpp -- see nvllm_host.hpp.
 #include "nvllm_host.hpp"
 
+#include <cmath>
+
 #include <unordered_map>
 
 namespace nvllm {
@@ -243,10 +245,28 @@ std::int64_t slot_mapping_last_writer(const std::int64_t *slots, std::int64_t n,
     return superseded;
 }
 
+bool rope_cache(std::size_t dim, std::size_t max_seq_len, double theta, float *cos_out,
+                float *sin_out) {
+    if (dim == 0 || (dim & 1)) return false;
+    const std::size_t half = dim / 2;
+    std::vector<float> inv_freq(half);
+    for (std::size_t i = 0; i < half; ++i)  // rope.rs:55-57: f64 powf, stored as f32
+        inv_freq[i] = static_cast<float>(1.0 / std::pow(theta, 2.0 * (double)i / (double)dim));
+    for (std::size_t p = 0; p < max_seq_len; ++p)
+        for (std::size_t i = 0; i < half; ++i) {
+            const float f = static_cast<float>(p) * inv_freq[i];  // rope.rs:65 broadcast_mul in f32
+            const float c = std::cos(f), sn = std::sin(f);
+            cos_out[p * dim + i] = cos_out[p * dim + half + i] = c;  // rope.rs:69 cat(freqs, freqs)
+            sin_out[p * dim + i] = sin_out[p * dim + half + i] = sn;
+        }
+    return true;
+}
+
 void BatchMetadata::clear() {
     block_tables_.clear();
     context_lens_.clear();
     slot_mapping_.clear();
+    positions_.clear();
     query_start_.assign(1, 0);
 }
 
@@ -271,8 +291,10 @@ Error BatchMetadata::add_sequence(const BlockTable &table, std::size_t context_l
         block_tables_.push_back(static_cast<std::int32_t>(id));
     }
     context_lens_.push_back(static_cast<std::int32_t>(context_len));
-    for (std::size_t p = context_len - num_new_tokens; p < context_len; ++p)  // block.rs:272-279
+    for (std::size_t p = context_len - num_new_tokens; p < context_len; ++p) {  // block.rs:272-279
         slot_mapping_.push_back(static_cast<std::int64_t>(ids[p / bs] * bs + p % bs));
+        positions_.push_back(static_cast<std::int32_t>(p));
+    }
     query_start_.push_back(static_cast<std::int32_t>(slot_mapping_.size()));
     return Error{};
 }

@@ -110,6 +110,11 @@ class BlockTable {
 //   context_lens  int32 [num_seqs]                        (context INCLUDING the new tokens)
 //   slot_mapping  int64 [num_tokens]                      (new tokens of all sequences, in order)
 //   query_start   int32 [num_seqs + 1]                    (first new-token row of each sequence)
+// rope.rs:42-80 RotaryEmbedding::new: cos / sin tables [max_seq_len, dim] in f32 (the caller
+// converts to the model dtype like to_dtype there).  false when dim is odd or not positive.
+bool rope_cache(std::size_t dim, std::size_t max_seq_len, double theta, float *cos_out,
+                float *sin_out);
+
 class BatchMetadata {
   public:
     explicit BatchMetadata(std::size_t max_blocks_per_seq) : max_blocks_(max_blocks_per_seq) {
@@ -127,10 +132,12 @@ class BatchMetadata {
     const std::vector<std::int32_t> &context_lens() const { return context_lens_; }
     const std::vector<std::int64_t> &slot_mapping() const { return slot_mapping_; }
     const std::vector<std::int32_t> &query_start() const { return query_start_; }
+    // position of every new token inside its sequence (RoPE row; rope.rs:107-113 start_pos + i)
+    const std::vector<std::int32_t> &positions() const { return positions_; }
 
   private:
     std::size_t max_blocks_;
-    std::vector<std::int32_t> block_tables_, context_lens_, query_start_;
+    std::vector<std::int32_t> block_tables_, context_lens_, query_start_, positions_;
     std::vector<std::int64_t> slot_mapping_;
 };
 

@@ -17,6 +17,32 @@ hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_
                                     int64_t num_tokens, int64_t row_bytes, int64_t num_slots,
                                     hipStream_t stream);
 
+// K5: qk_norm_rope_cache.hip
+struct QkNormRopeCacheArgs {
+    const void *q;
+    const void *k;
+    const void *v;
+    void *q_out;
+    void *k_out;  // optional
+    const void *q_weight;
+    const void *k_weight;
+    float eps;
+    const void *cos_cache;
+    const void *sin_cache;
+    int max_positions;
+    const int32_t *positions;
+    void *k_cache;
+    void *v_cache;
+    const int64_t *slot_mapping;
+    int64_t num_tokens;
+    int num_heads;
+    int num_kv_heads;
+    int head_dim;
+    int block_size;
+    int64_t num_cache_blocks;
+};
+hipError_t launch_qk_norm_rope_cache(DType dt, const QkNormRopeCacheArgs &a, hipStream_t stream);
+
 // K2/K2b/K3: paged_attn.hip
 struct PagedAttnArgs {
     const void *q;

@@ -410,6 +410,72 @@ int oracle_write_kv_to_cache(const float *key, const float *value, float *key_ca
     return ORACLE_OK;
 }
 
+/* src/model/norm.rs:83-100  RmsNorm::forward over the last dimension:
+ *   x_squared = x.sqr(); variance = mean_keepdim(-1); rms = sqrt(variance + eps);
+ *   normalized = x / rms; out = normalized * weight.
+ * f32 like every op of the f32 tensors the reference tests run on; candle's mean_keepdim is
+ * sum / n.  Used per head on Q and K (src/model/attention.rs:229-231,352-357: the norm sees
+ * [B,S,H,D] and normalises D).  rows = product of the leading dims.              */
+int oracle_rms_norm(const float *x, const float *weight, double eps, int64_t rows, int64_t D,
+                    float *out) {
+    if (D <= 0) return ORACLE_ERR_CONFIG;
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *xr = x + r * D;
+        float sum = 0.0f;
+        for (int64_t i = 0; i < D; ++i) sum += xr[i] * xr[i];
+        const float variance = sum / (float)D;
+        const float rms = sqrtf((float)((double)variance + eps)); /* (variance + eps)?.sqrt() */
+        for (int64_t i = 0; i < D; ++i) out[r * D + i] = (xr[i] / rms) * weight[i];
+    }
+    return ORACLE_OK;
+}
+
+/* src/model/rope.rs:42-80  RotaryEmbedding::new: inv_freq[i] = (1 / theta^(2i/dim)) computed in
+ * f64 and stored as f32; freqs[p][i] = (p as f32) * inv_freq[i] in f32; the row is
+ * cat(freqs, freqs) (so column i and i + dim/2 are equal); cos/sin taken in f32.
+ * cos, sin: [max_seq_len, dim].                                                */
+int oracle_rope_cache(int64_t dim, int64_t max_seq_len, double theta, float *cos_out,
+                      float *sin_out) {
+    if (dim <= 0 || (dim & 1)) return ORACLE_ERR_CONFIG; /* assert!(dim.is_multiple_of(2)) */
+    const int64_t half = dim / 2;
+    for (int64_t p = 0; p < max_seq_len; ++p)
+        for (int64_t i = 0; i < half; ++i) {
+            const float inv_freq = (float)(1.0 / pow(theta, 2.0 * (double)i / (double)dim));
+            const float f = (float)p * inv_freq;
+            const float c = cosf(f), sn = sinf(f);
+            cos_out[p * dim + i] = c;
+            cos_out[p * dim + half + i] = c;
+            sin_out[p * dim + i] = sn;
+            sin_out[p * dim + half + i] = sn;
+        }
+    return ORACLE_OK;
+}
+
+/* src/model/rope.rs:107-152  apply + apply_rotation + rotate_half on one tensor x [B,S,H,D]:
+ *   cos/sin rows start_pos .. start_pos+S (narrow: past the cache -> Tensor error);
+ *   rotate_half(x) = cat(-x[half:], x[:half]);  out = x * cos + rotate_half(x) * sin.    */
+int oracle_rope_apply(const float *x, const float *cos_cache, const float *sin_cache,
+                      int64_t max_seq_len, int64_t start_pos, int64_t B, int64_t S, int64_t H,
+                      int64_t D, float *out) {
+    if (D <= 0 || (D & 1)) return ORACLE_ERR_CONFIG;
+    if (start_pos < 0 || start_pos + S > max_seq_len) return ORACLE_ERR_TENSOR;
+    const int64_t half = D / 2;
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t s = 0; s < S; ++s) {
+            const float *c = cos_cache + (start_pos + s) * D;
+            const float *sn = sin_cache + (start_pos + s) * D;
+            for (int64_t h = 0; h < H; ++h) {
+                const float *xr = x + ((b * S + s) * H + h) * D;
+                float *o = out + ((b * S + s) * H + h) * D;
+                for (int64_t i = 0; i < half; ++i) {
+                    o[i] = xr[i] * c[i] + (-xr[i + half]) * sn[i];
+                    o[i + half] = xr[i + half] * c[i + half] + xr[i] * sn[i + half];
+                }
+            }
+        }
+    return ORACLE_OK;
+}
+
 /* Thread count the OpenMP loops above will use (reported as cpu_baseline.cores). */
 #ifdef _OPENMP
 #include <omp.h>

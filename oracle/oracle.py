@@ -17,6 +17,7 @@ __all__ = [
     "compute_num_blocks", "get_slot_mapping", "hash_token_block", "siphash",
     "flash_attention_cpu", "prefill_attention", "paged_attention",
     "write_kv_to_cache", "num_threads", "naive_sdpa", "bf16_round",
+    "rms_norm", "rope_cache", "rope_apply", "qk_norm_rope",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -69,6 +70,12 @@ def lib():
             ctypes.c_double, f32p]
         L.oracle_write_kv_to_cache.restype = ctypes.c_int
         L.oracle_write_kv_to_cache.argtypes = [f32p, f32p, f32p, f32p, i64p] + [i64] * 6
+        L.oracle_rms_norm.restype = ctypes.c_int
+        L.oracle_rms_norm.argtypes = [f32p, f32p, ctypes.c_double, i64, i64, f32p]
+        L.oracle_rope_cache.restype = ctypes.c_int
+        L.oracle_rope_cache.argtypes = [i64, i64, ctypes.c_double, f32p, f32p]
+        L.oracle_rope_apply.restype = ctypes.c_int
+        L.oracle_rope_apply.argtypes = [f32p, f32p, f32p] + [i64] * 6 + [f32p]
         L.oracle_num_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -180,6 +187,40 @@ def write_kv_to_cache(key, value, key_cache, value_cache, slot_mapping, block_si
     _check(lib().oracle_write_kv_to_cache(_p(key), _p(value), _p(kc), _p(vc), _pi(slots),
                                           slots.size, S, nb, bs, Hkv, D))
     return kc, vc
+
+
+def rms_norm(x, weight, eps):
+    """norm.rs:83-100 over the last dimension."""
+    x, weight = _f32(x), _f32(weight)
+    D = x.shape[-1]
+    out = np.empty_like(x)
+    _check(lib().oracle_rms_norm(_p(x), _p(weight), float(eps), x.size // D, D, _p(out)))
+    return out
+
+
+def rope_cache(dim, max_seq_len, theta):
+    """rope.rs:42-80 -> (cos, sin), each [max_seq_len, dim] f32."""
+    cos = np.empty((max_seq_len, dim), dtype=np.float32)
+    sin = np.empty((max_seq_len, dim), dtype=np.float32)
+    _check(lib().oracle_rope_cache(dim, max_seq_len, float(theta), _p(cos), _p(sin)))
+    return cos, sin
+
+
+def rope_apply(x, cos, sin, start_pos):
+    """rope.rs:107-152 on one tensor x [B,S,H,D] (apply() runs it on q and on k)."""
+    x, cos, sin = _f32(x), _f32(cos), _f32(sin)
+    B, S, H, D = x.shape
+    out = np.empty_like(x)
+    _check(lib().oracle_rope_apply(_p(x), _p(cos), _p(sin), cos.shape[0], start_pos, B, S, H, D,
+                                   _p(out)))
+    return out
+
+
+def qk_norm_rope(q, k, q_weight, k_weight, eps, cos, sin, start_pos):
+    """Steps 3-4 of Qwen3Attention::forward (src/model/attention.rs:229-234): per-head RMSNorm
+    on Q and K, then RoPE from start_pos.  q [B,S,Hq,D], k [B,S,Hkv,D]."""
+    qn, kn = rms_norm(q, q_weight, eps), rms_norm(k, k_weight, eps)
+    return rope_apply(qn, cos, sin, start_pos), rope_apply(kn, cos, sin, start_pos)
 
 
 def naive_sdpa(q, k, v, scale, causal):

@@ -19,7 +19,7 @@ def test_matches_per_sequence_slot_mapping():
     rng = np.random.default_rng(0)
     bs = 16
     batch = nv.BatchMetadata(8)
-    want_slots, want_ctx, want_tables, starts = [], [], [], [0]
+    want_slots, want_ctx, want_tables, starts, want_pos = [], [], [], [0], []
     for _ in range(9):
         nblk = int(rng.integers(1, 9))
         ids = rng.choice(1000, size=nblk, replace=False).tolist()
@@ -29,6 +29,7 @@ def test_matches_per_sequence_slot_mapping():
         batch.add_sequence(t, ctx, new)
         full = t.get_slot_mapping(ctx)          # the reference's mapping of the whole context
         want_slots += full[ctx - new:]
+        want_pos += list(range(ctx - new, ctx))   # rope.rs:107-113: start_pos + i
         want_ctx.append(ctx)
         want_tables.append(ids + [0] * (8 - nblk))
         starts.append(starts[-1] + new)
@@ -37,6 +38,7 @@ def test_matches_per_sequence_slot_mapping():
     assert batch.context_lens().tolist() == want_ctx
     assert batch.block_tables().tolist() == want_tables
     assert batch.query_start().tolist() == starts
+    assert batch.positions().tolist() == want_pos and batch.positions().dtype == np.int32
     assert batch.block_tables().dtype == np.int32 and batch.slot_mapping().dtype == np.int64
 
 

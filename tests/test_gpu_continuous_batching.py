@@ -58,7 +58,7 @@ def test_mixed_prefill_decode_verify_with_rollback(dev):
                 while tables[i].num_blocks() < nv.compute_num_blocks(total, bs):
                     tables[i].append_block(mgr.allocate())
                 batch.add_sequence(tables[i], total, tcur)
-            bt, cl, sm, qs = batch.upload(dev)
+            bt, cl, sm, qs, _ps = batch.upload(dev)
             assert qs.cpu().tolist() == [tcur * j for j in range(len(group) + 1)]
             to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, torch.bfloat16)
             nv.reshape_and_cache(to(k_new.reshape(-1, Hkv, D)), to(v_new.reshape(-1, Hkv, D)), kc, vc, sm)
