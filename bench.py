@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the attention hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|prefill|kvwrite]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|prefill|kvwrite|producer]
 
 Headline (default, BASELINE.json `metric`): paged-decode attention GB/s on
 BASELINE config 3 -- 256 sequences x 2048-token contexts, 32 Q / 8 KV heads,
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="decode",
-                    choices=["decode", "shared", "long", "prefill", "kvwrite"])
+                    choices=["decode", "shared", "long", "prefill", "kvwrite", "producer"])
     ap.add_argument("--num-seqs", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=0)
     ap.add_argument("--layers", type=int, default=0, help="disjoint layer caches rotated over")
@@ -326,6 +326,39 @@ def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
                               traffic=None, kernel="reshape_and_cache_kernel", launch_ms=ev_ms))
 
 
+def run_producer(args, nv, dev, rank, world, steps, warmup, num_tokens):
+    """K5: per-head RMSNorm + RoPE + KV write over one step's new tokens (Qwen3-4B head shape)."""
+    Hq, Hkv, D, bs = 32, 8, 128, 16
+    nb = max(2 * num_tokens // bs, 4096)
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    nbuf = 4                                   # rotate so the caches do not serve the re-reads
+    bufs = []
+    for _ in range(nbuf):
+        bufs.append((torch.randn((num_tokens, Hq, D), generator=g).to(dev, torch.bfloat16),
+                     torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16),
+                     torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16),
+                     torch.zeros((nb, bs, Hkv, D), dtype=torch.bfloat16, device=dev),
+                     torch.zeros((nb, bs, Hkv, D), dtype=torch.bfloat16, device=dev)))
+    w = torch.ones(D, dtype=torch.bfloat16, device=dev)
+    rot = nv.RotaryEmbedding(D, 40960, 1e6, torch.bfloat16, dev)
+    pos = torch.randint(0, 40960, (num_tokens,), generator=g).to(dev, torch.int32)
+    slots = torch.randperm(nb * bs, generator=g)[:num_tokens].to(dev)
+
+    def step(i):
+        q, k, v, kc, vc = bufs[i % nbuf]
+        nv.qk_norm_rope_cache(q, k, v, w, w, 1e-6, rot, pos, kc, vc, slots)
+
+    wall, ev_ms = timed_loop(step, steps, warmup, world, dev)
+    bytes_moved = num_tokens * ((2 * Hq + 4 * Hkv) * D * 2 + 2 * D * 2 + 12)
+    return dict(metric="qk_norm_rope_cache_GBps", unit="GB/s", value=world * bytes_moved * steps / wall / 1e9,
+                ms_per_step=wall / steps * 1e3,
+                config=dict(workload="qk_norm_rope_cache, %d tokens, 32Q/8KV, hd128, bf16" % num_tokens,
+                            algorithmic_bytes_per_step_per_gpu=bytes_moved),
+                roofline=dict(bound="hbm", achieved=bytes_moved / (ev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                              unit="GB/s", frac=bytes_moved / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              traffic=None, kernel="qk_norm_rope_cache_d128_kernel", launch_ms=ev_ms))
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled
@@ -352,6 +385,8 @@ def main():
             res["roofline"]["traffic"] = pmc_traffic("config3_decode")
     elif args.workload == "prefill":
         res = run_prefill(args, nv, dev, rank, world, args.steps, args.warmup)
+    elif args.workload == "producer":
+        res = run_producer(args, nv, dev, rank, world, args.steps, args.warmup, args.num_seqs or 32768)
     else:
         res = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, args.num_seqs or 4096)
     also = {}
@@ -366,6 +401,11 @@ def main():
             w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, n)
             also["kv_write_%d" % n] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
                                            frac=w["roofline"]["frac"])
+        for n in (256, 32768):
+            w = run_producer(args, nv, dev, rank, world, args.steps, args.warmup, n)
+            also["qk_norm_rope_cache_%d" % n] = dict(value=w["value"], unit="GB/s",
+                                                     ms_per_step=w["ms_per_step"],
+                                                     frac=w["roofline"]["frac"])
     props = torch.cuda.get_device_properties(dev)
     line = dict(
         metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=world, steps=args.steps,

@@ -14,10 +14,11 @@
 //   + 2*D*elt of cos/sin (shared by the token's heads) + 12 B (slot, position);
 // Qwen3-4B shapes, bf16: 24.5 KiB per token.
 //
-// Mapping (fast path, bf16, D = 128): a "row" is one head of one token, 256 B.  16 lanes per
-// row, 4 rows per wave; lane i holds elements [4i, 4i+4) and [64+4i, 64+4i+4), i.e. both halves
-// of its rotation pairs, so the rotation is lane-local and the only cross-lane step is the
-// 16-lane sum of squares.  All arithmetic in f32, one rounding to bf16 at the end.
+// Mapping (fast path, bf16, D = 128): a "row" is one head of one token, 256 B.  8 lanes per
+// row, 8 rows per wave; lane i holds elements [8i, 8i+8) and [64+8i, 64+8i+8) (two 16-byte
+// accesses), i.e. both halves of its rotation pairs, so the rotation is lane-local and the only
+// cross-lane step is the 8-lane sum of squares.  Q/K/V are read once: non-temporal loads.  All
+// arithmetic in f32, one rounding to bf16 at the end.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,7 +30,7 @@ namespace kernels {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned w) {
@@ -42,14 +43,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     r[1] = static_cast<__bf16>(hi);
     return __builtin_bit_cast(unsigned, r);
 }
-__device__ __forceinline__ void unpack4(u32x2 w, float *x) {
-    x[0] = bf16_lo(w[0]);
-    x[1] = bf16_hi(w[0]);
-    x[2] = bf16_lo(w[1]);
-    x[3] = bf16_hi(w[1]);
-}
+constexpr int kRowsPerBlock = 32;  // 256 threads, 8 lanes per row
 
-constexpr int kRowsPerBlock = 16;  // 256 threads, 16 lanes per row
+__device__ __forceinline__ void unpack8(u32x4 w, float *x) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[2 * i] = bf16_lo(w[i]);
+        x[2 * i + 1] = bf16_hi(w[i]);
+    }
+}
 
 __global__ __launch_bounds__(256) void qk_norm_rope_cache_d128_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
@@ -60,13 +62,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_cache_d128_kernel(
     const int64_t *__restrict__ slot_mapping, int64_t num_rows, int Hq, int Hkv,
     int64_t num_slots) {
     constexpr int D = 128;
-    const int li = threadIdx.x & 15;
-    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 4);
-    if (row >= num_rows) return;  // whole 16-lane groups leave together
+    const int li = threadIdx.x & 7;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 3);
+    if (row >= num_rows) return;  // whole 8-lane groups leave together
     const int R = Hq + 2 * Hkv;
     const int64_t tok = row / R;
     const int j = (int)(row - tok * R);
-    const int off_lo = 4 * li, off_hi = 64 + 4 * li;
+    const int off_lo = 8 * li, off_hi = 64 + 8 * li;
 
     if (j >= Hq + Hkv) {  // V head: copy into the cache slot
         const int hv = j - Hq - Hkv;
@@ -74,10 +76,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_cache_d128_kernel(
         if (slot < 0 || slot >= num_slots) return;
         const __bf16 *src = v + (tok * Hkv + hv) * D;
         __bf16 *dst = v_cache + (slot * Hkv + hv) * D;
-        const u32x2 lo = *reinterpret_cast<const u32x2 *>(src + off_lo);
-        const u32x2 hi = *reinterpret_cast<const u32x2 *>(src + off_hi);
-        *reinterpret_cast<u32x2 *>(dst + off_lo) = lo;
-        *reinterpret_cast<u32x2 *>(dst + off_hi) = hi;
+        const u32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off_lo));
+        const u32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off_hi));
+        *reinterpret_cast<u32x4 *>(dst + off_lo) = lo;
+        *reinterpret_cast<u32x4 *>(dst + off_hi) = hi;
         return;
     }
     const bool is_q = j < Hq;
@@ -86,58 +88,60 @@ __global__ __launch_bounds__(256) void qk_norm_rope_cache_d128_kernel(
     const __bf16 *w = is_q ? q_weight : k_weight;
     int pos = positions[tok];
     pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);  // never read outside the tables
-    const u32x2 xlo = *reinterpret_cast<const u32x2 *>(src + off_lo);
-    const u32x2 xhi = *reinterpret_cast<const u32x2 *>(src + off_hi);
-    const u32x2 wlo = *reinterpret_cast<const u32x2 *>(w + off_lo);
-    const u32x2 whi = *reinterpret_cast<const u32x2 *>(w + off_hi);
-    const u32x2 clo = *reinterpret_cast<const u32x2 *>(cos_cache + (int64_t)pos * D + off_lo);
-    const u32x2 chi = *reinterpret_cast<const u32x2 *>(cos_cache + (int64_t)pos * D + off_hi);
-    const u32x2 slo = *reinterpret_cast<const u32x2 *>(sin_cache + (int64_t)pos * D + off_lo);
-    const u32x2 shi = *reinterpret_cast<const u32x2 *>(sin_cache + (int64_t)pos * D + off_hi);
+    const u32x4 xlo = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off_lo));
+    const u32x4 xhi = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off_hi));
+    const u32x4 wlo = *reinterpret_cast<const u32x4 *>(w + off_lo);
+    const u32x4 whi = *reinterpret_cast<const u32x4 *>(w + off_hi);
+    const u32x4 clo = *reinterpret_cast<const u32x4 *>(cos_cache + (int64_t)pos * D + off_lo);
+    const u32x4 chi = *reinterpret_cast<const u32x4 *>(cos_cache + (int64_t)pos * D + off_hi);
+    const u32x4 slo = *reinterpret_cast<const u32x4 *>(sin_cache + (int64_t)pos * D + off_lo);
+    const u32x4 shi = *reinterpret_cast<const u32x4 *>(sin_cache + (int64_t)pos * D + off_hi);
     int64_t slot = -1;
     if (!is_q) slot = slot_mapping[tok];
 
-    float x1[4], x2[4], w1[4], w2[4], c1[4], c2[4], s1[4], s2[4];
-    unpack4(xlo, x1);
-    unpack4(xhi, x2);
-    unpack4(wlo, w1);
-    unpack4(whi, w2);
-    unpack4(clo, c1);
-    unpack4(chi, c2);
-    unpack4(slo, s1);
-    unpack4(shi, s2);
+    float x1[8], x2[8], w1[8], w2[8], c1[8], c2[8], s1[8], s2[8];
+    unpack8(xlo, x1);
+    unpack8(xhi, x2);
+    unpack8(wlo, w1);
+    unpack8(whi, w2);
+    unpack8(clo, c1);
+    unpack8(chi, c2);
+    unpack8(slo, s1);
+    unpack8(shi, s2);
     float ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ss += x1[i] * x1[i] + x2[i] * x2[i];
+    for (int i = 0; i < 8; ++i) ss += x1[i] * x1[i] + x2[i] * x2[i];
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m);
+    for (int m = 1; m < 8; m <<= 1) ss += __shfl_xor(ss, m);
     const float inv = 1.0f / sqrtf(ss * (1.0f / D) + eps);
-    float y1[4], y2[4];
+    u32x4 olo, ohi;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float n1 = x1[i] * inv * w1[i], n2 = x2[i] * inv * w2[i];
-        y1[i] = n1 * c1[i] - n2 * s1[i];  // x*cos + (-x2)*sin   (rope.rs:131-151)
-        y2[i] = n2 * c2[i] + n1 * s2[i];  // x*cos + ( x1)*sin
+        float y1[2], y2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = 2 * i + e;
+            const float n1 = x1[t] * inv * w1[t], n2 = x2[t] * inv * w2[t];
+            y1[e] = n1 * c1[t] - n2 * s1[t];  // x*cos + (-x2)*sin   (rope.rs:131-151)
+            y2[e] = n2 * c2[t] + n1 * s2[t];  // x*cos + ( x1)*sin
+        }
+        olo[i] = pack_bf16x2(y1[0], y1[1]);
+        ohi[i] = pack_bf16x2(y2[0], y2[1]);
     }
-    u32x2 olo, ohi;
-    olo[0] = pack_bf16x2(y1[0], y1[1]);
-    olo[1] = pack_bf16x2(y1[2], y1[3]);
-    ohi[0] = pack_bf16x2(y2[0], y2[1]);
-    ohi[1] = pack_bf16x2(y2[2], y2[3]);
     if (is_q) {
         __bf16 *dst = q_out + (tok * Hq + j) * D;
-        *reinterpret_cast<u32x2 *>(dst + off_lo) = olo;
-        *reinterpret_cast<u32x2 *>(dst + off_hi) = ohi;
+        *reinterpret_cast<u32x4 *>(dst + off_lo) = olo;
+        *reinterpret_cast<u32x4 *>(dst + off_hi) = ohi;
     } else {
         if (k_out) {
             __bf16 *dst = k_out + (tok * Hkv + hk) * D;
-            *reinterpret_cast<u32x2 *>(dst + off_lo) = olo;
-            *reinterpret_cast<u32x2 *>(dst + off_hi) = ohi;
+            *reinterpret_cast<u32x4 *>(dst + off_lo) = olo;
+            *reinterpret_cast<u32x4 *>(dst + off_hi) = ohi;
         }
         if (slot >= 0 && slot < num_slots) {
             __bf16 *dst = k_cache + (slot * Hkv + hk) * D;
-            *reinterpret_cast<u32x2 *>(dst + off_lo) = olo;
-            *reinterpret_cast<u32x2 *>(dst + off_hi) = ohi;
+            *reinterpret_cast<u32x4 *>(dst + off_lo) = olo;
+            *reinterpret_cast<u32x4 *>(dst + off_hi) = ohi;
         }
     }
 }
@@ -209,7 +213,7 @@ hipError_t launch_qk_norm_rope_cache(DType dt, const QkNormRopeCacheArgs &a, hip
     if (a.num_tokens <= 0) return hipSuccess;
     const int64_t rows = a.num_tokens * (a.num_heads + 2 * a.num_kv_heads);
     const int64_t num_slots = a.num_cache_blocks * a.block_size;
-    const auto al8 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+    const auto al8 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (dt == DType::BF16 && a.head_dim == 128 && al8(a.q) && al8(a.k) && al8(a.v) && al8(a.q_out) &&
         al8(a.k_out) && al8(a.q_weight) && al8(a.k_weight) && al8(a.cos_cache) &&
         al8(a.sin_cache) && al8(a.k_cache) && al8(a.v_cache)) {
