@@ -302,6 +302,84 @@ int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_conte
                        void *d_slot_mapping, void *d_query_start, void *d_positions,
                        nvllm_stream_t stream);
 
+/* --- Scheduler + Sequence (src/scheduler/batch.rs:60-512, src/core/sequence.rs:10-327) ------
+ * The caller of the attention path: decides, step by step, which sequences prefill (and how
+ * many tokens) and which decode, and owns their block tables.  Decisions are the reference's,
+ * step for step, with its defaults (src/config.rs:59-69).  Two extra switches, both off by
+ * default, repair what SURVEY 8f-1 lists: reschedule_partial_prefill (a chunk-prefilled sequence
+ * gets its next chunk; the reference never schedules it again) and enable_prefix_caching
+ * (admission reuses cached full prompt blocks through hash_token_block + the BlockManager prefix
+ * cache; src/config.rs:22 declares the flag, nothing reads it there). */
+typedef struct nvllm_scheduler nvllm_scheduler;
+typedef struct nvllm_scheduler_config {      /* SchedulerConfig, src/config.rs:44-57 */
+    int64_t max_num_seqs;
+    int64_t max_prefill_tokens;
+    int enable_chunked_prefill;
+    int64_t chunk_size;
+    int enable_priority;
+    int enable_preemption;
+    int reschedule_partial_prefill;          /* extension, default 0 */
+    int enable_prefix_caching;               /* extension, default 0 */
+} nvllm_scheduler_config;
+void nvllm_scheduler_config_default(nvllm_scheduler_config *c);               /* config.rs:59-69 */
+nvllm_scheduler *nvllm_scheduler_new(const nvllm_scheduler_config *c, int64_t block_size,
+                                     int64_t num_blocks);                      /* batch.rs:166 */
+void nvllm_scheduler_free(nvllm_scheduler *s);
+/* Sequence::with_priority (sequence.rs:131) + Scheduler::add_sequence (batch.rs:181) */
+int nvllm_scheduler_add_sequence(nvllm_scheduler *s, uint64_t seq_id, const uint32_t *prompt,
+                                 int64_t num_tokens, int32_t priority);
+int nvllm_scheduler_remove_sequence(nvllm_scheduler *s, uint64_t seq_id);      /* :198; 1 / 0 */
+/* Scheduler::schedule (batch.rs:227); the SchedulerOutputs stay readable until the next call */
+int nvllm_scheduler_schedule(nvllm_scheduler *s);
+int64_t nvllm_scheduler_out_num_prefill(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_out_num_decode(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_out_num_preempted(const nvllm_scheduler *s);
+const uint64_t *nvllm_scheduler_out_prefill_ids(const nvllm_scheduler *s);
+const uint64_t *nvllm_scheduler_out_decode_ids(const nvllm_scheduler *s);
+const uint64_t *nvllm_scheduler_out_preempted_ids(const nvllm_scheduler *s);
+/* prefill_chunk_sizes (batch.rs:66-68) in the order of the prefill ids */
+const int64_t *nvllm_scheduler_out_prefill_chunk_sizes(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_out_num_prefill_tokens(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_out_num_decode_tokens(const nvllm_scheduler *s);
+/* reason: 0 EndOfSequence, 1 MaxTokens, 2 StopSequence, 3 Aborted (sequence.rs:51-60) */
+void nvllm_scheduler_finish_sequence(nvllm_scheduler *s, uint64_t seq_id, int reason); /* :428 */
+int nvllm_scheduler_append_token(nvllm_scheduler *s, uint64_t seq_id, uint32_t token); /* :442 */
+int nvllm_scheduler_mark_prefilled(nvllm_scheduler *s, uint64_t seq_id, int64_t num_tokens); /* :452 */
+int64_t nvllm_scheduler_num_waiting(const nvllm_scheduler *s);                 /* :462 */
+int64_t nvllm_scheduler_num_running(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_num_swapped(const nvllm_scheduler *s);
+int nvllm_scheduler_has_unfinished_sequences(const nvllm_scheduler *s);        /* :482 */
+int nvllm_scheduler_has_pending_requests(const nvllm_scheduler *s);            /* :489 */
+/* copies up to cap ids, returns how many are running (:477) */
+int64_t nvllm_scheduler_running_sequence_ids(const nvllm_scheduler *s, uint64_t *out, int64_t cap);
+void nvllm_scheduler_reset(nvllm_scheduler *s);                                /* :504 */
+/* Sequence queries (get_sequence, :215): status 0 Waiting, 1 Running, 2 Swapped, 3 Finished
+ * (sequence.rs:16-25); -1 = no such sequence */
+int nvllm_scheduler_seq_status(const nvllm_scheduler *s, uint64_t seq_id);
+int nvllm_scheduler_seq_finish_reason(const nvllm_scheduler *s, uint64_t seq_id);
+/* get_sequence_mut + set_waiting / set_running / set_swapped (sequence.rs:254-301); a transition
+ * the reference rejects (Error::InvalidStateTransition) -> NVLLM_ERR_CONFIG */
+int nvllm_scheduler_seq_set_status(nvllm_scheduler *s, uint64_t seq_id, int status);
+/* what: 0 prompt_len, 1 output_len, 2 total_len, 3 num_prefilled_tokens, 4 num_tokens_to_prefill,
+ * 5 is_prefill_complete, 6 block_table().num_blocks(), 7 priority, 8 last_token_id (-1 = none) */
+int64_t nvllm_scheduler_seq_info(const nvllm_scheduler *s, uint64_t seq_id, int what);
+int64_t nvllm_scheduler_seq_block_ids(const nvllm_scheduler *s, uint64_t seq_id, int64_t *out,
+                                      int64_t cap);
+int64_t nvllm_scheduler_seq_output_tokens(const nvllm_scheduler *s, uint64_t seq_id, uint32_t *out,
+                                          int64_t cap);
+/* block_manager() view (:494) */
+int64_t nvllm_scheduler_num_free_blocks(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_num_used_blocks(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_num_cached_prefixes(const nvllm_scheduler *s);
+int64_t nvllm_scheduler_block_ref_count(const nvllm_scheduler *s, int64_t block_id);
+/* Last schedule() result -> batched-kernel metadata (appends to `batch`):
+ * decode: every decode sequence with one new token at position total_len - 1;
+ * prefill: the prefill sequences whose chunk is exactly num_new_tokens long (the kernels take one
+ * T per launch), their ids to ids_out; returns how many were added, or a negative status. */
+int nvllm_scheduler_fill_decode_batch(const nvllm_scheduler *s, nvllm_batch *batch);
+int64_t nvllm_scheduler_fill_prefill_batch(const nvllm_scheduler *s, int64_t num_new_tokens,
+                                           nvllm_batch *batch, uint64_t *ids_out, int64_t cap);
+
 /* paged_attention exactly as src/attention/paged.rs:117-126 takes it: one
  * sequence, a host BlockTable, the layer's cache.  Validates like the
  * reference (empty table -> NVLLM_ERR_CONFIG, paged.rs:133-137; batch != 1 or

@@ -10,6 +10,8 @@ this package falls back to PyTorch or to the CPU oracle.
 """
 from . import capi  # noqa: F401
 from . import sharding  # noqa: F401
+from . import scheduler  # noqa: F401
+from .scheduler import Scheduler, SchedulerConfig, SchedulerOutputs  # noqa: F401
 from .core import (  # noqa: F401
     DEFAULT_BLOCK_SIZE, BlockTable, BlockManager, BatchMetadata, KVCacheConfig, LayerKVCache, KVCache,
     compute_num_blocks, hash_token_block, NvllmError, ConfigError, OutOfBlocksError,

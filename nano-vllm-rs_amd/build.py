@@ -13,6 +13,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libnvllm_attn.so")
 SOURCES = [
     "nvllm_host.cpp",
+    "nvllm_sched.cpp",
     "capi.cpp",
     "reshape_and_cache.hip",
     "qk_norm_rope_cache.hip",
@@ -20,7 +21,7 @@ SOURCES = [
     "flash_attn.hip",
     "flash_attn_mfma.hip",
 ]
-HEADERS = ["nvllm_host.hpp", "nvllm_kernels.hpp", os.path.join("..", "..", "include", "nvllm_attn.h")]
+HEADERS = ["nvllm_host.hpp", "nvllm_sched.hpp", "nvllm_kernels.hpp", os.path.join("..", "..", "include", "nvllm_attn.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]

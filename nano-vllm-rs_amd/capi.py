@@ -53,6 +53,43 @@ SIGNATURES = {
     "nvllm_block_table_get_block_id": (_i, [_vp, _i64, _pi64]),
     "nvllm_block_table_get_physical_block_ids": (_i64, [_vp, _pi64, _i64]),
     "nvllm_block_table_get_slot_mapping": (_i64, [_vp, _i64, _pi64, _i64]),
+    "nvllm_scheduler_config_default": (None, [_vp]),
+    "nvllm_scheduler_new": (_vp, [_vp, _i64, _i64]),
+    "nvllm_scheduler_free": (None, [_vp]),
+    "nvllm_scheduler_add_sequence": (_i, [_vp, _u64, _vp, _i64, _c.c_int32]),
+    "nvllm_scheduler_remove_sequence": (_i, [_vp, _u64]),
+    "nvllm_scheduler_schedule": (_i, [_vp]),
+    "nvllm_scheduler_out_num_prefill": (_i64, [_vp]),
+    "nvllm_scheduler_out_num_decode": (_i64, [_vp]),
+    "nvllm_scheduler_out_num_preempted": (_i64, [_vp]),
+    "nvllm_scheduler_out_prefill_ids": (_vp, [_vp]),
+    "nvllm_scheduler_out_decode_ids": (_vp, [_vp]),
+    "nvllm_scheduler_out_preempted_ids": (_vp, [_vp]),
+    "nvllm_scheduler_out_prefill_chunk_sizes": (_vp, [_vp]),
+    "nvllm_scheduler_out_num_prefill_tokens": (_i64, [_vp]),
+    "nvllm_scheduler_out_num_decode_tokens": (_i64, [_vp]),
+    "nvllm_scheduler_finish_sequence": (None, [_vp, _u64, _i]),
+    "nvllm_scheduler_append_token": (_i, [_vp, _u64, _c.c_uint32]),
+    "nvllm_scheduler_mark_prefilled": (_i, [_vp, _u64, _i64]),
+    "nvllm_scheduler_num_waiting": (_i64, [_vp]),
+    "nvllm_scheduler_num_running": (_i64, [_vp]),
+    "nvllm_scheduler_num_swapped": (_i64, [_vp]),
+    "nvllm_scheduler_has_unfinished_sequences": (_i, [_vp]),
+    "nvllm_scheduler_has_pending_requests": (_i, [_vp]),
+    "nvllm_scheduler_running_sequence_ids": (_i64, [_vp, _vp, _i64]),
+    "nvllm_scheduler_reset": (None, [_vp]),
+    "nvllm_scheduler_seq_status": (_i, [_vp, _u64]),
+    "nvllm_scheduler_seq_finish_reason": (_i, [_vp, _u64]),
+    "nvllm_scheduler_seq_set_status": (_i, [_vp, _u64, _i]),
+    "nvllm_scheduler_seq_info": (_i64, [_vp, _u64, _i]),
+    "nvllm_scheduler_seq_block_ids": (_i64, [_vp, _u64, _vp, _i64]),
+    "nvllm_scheduler_seq_output_tokens": (_i64, [_vp, _u64, _vp, _i64]),
+    "nvllm_scheduler_num_free_blocks": (_i64, [_vp]),
+    "nvllm_scheduler_num_used_blocks": (_i64, [_vp]),
+    "nvllm_scheduler_num_cached_prefixes": (_i64, [_vp]),
+    "nvllm_scheduler_block_ref_count": (_i64, [_vp, _i64]),
+    "nvllm_scheduler_fill_decode_batch": (_i, [_vp, _vp]),
+    "nvllm_scheduler_fill_prefill_batch": (_i64, [_vp, _i64, _vp, _vp, _i64]),
     "nvllm_batch_new": (_vp, [_i64]),
     "nvllm_batch_free": (None, [_vp]),
     "nvllm_batch_clear": (None, [_vp]),

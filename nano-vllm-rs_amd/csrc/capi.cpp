@@ -13,6 +13,7 @@
 #include "../../include/nvllm_attn.h"
 #include "nvllm_host.hpp"
 #include "nvllm_kernels.hpp"
+#include "nvllm_sched.hpp"
 
 using nvllm::ErrorKind;
 using nvllm::set_last_error;
@@ -26,6 +27,12 @@ struct nvllm_block_table {
 struct nvllm_batch {
     core::BatchMetadata meta;
     explicit nvllm_batch(std::size_t mb) : meta(mb) {}
+};
+struct nvllm_scheduler {
+    core::Scheduler sched;
+    core::SchedulerOutputs out;                  // result of the last schedule()
+    std::vector<int64_t> out_chunk_sizes;        // aligned with out.prefill_sequences
+    nvllm_scheduler(const core::SchedulerConfig &c, std::size_t bs, std::size_t nb) : sched(c, bs, nb) {}
 };
 struct nvllm_block_manager {
     core::BlockManager mgr;
@@ -367,6 +374,174 @@ int nvllm_batch_upload(const nvllm_batch *b, void *d_block_tables, void *d_conte
     if (err == hipSuccess) err = hipStreamSynchronize(st);  // the host arrays are pageable
     if (err != hipSuccess) return hip_status(err, "batch upload");
     return NVLLM_OK;
+}
+
+void nvllm_scheduler_config_default(nvllm_scheduler_config *c) {
+    if (!c) return;
+    const core::SchedulerConfig d;  // config.rs:59-69
+    c->max_num_seqs = (int64_t)d.max_num_seqs;
+    c->max_prefill_tokens = (int64_t)d.max_prefill_tokens;
+    c->enable_chunked_prefill = d.enable_chunked_prefill;
+    c->chunk_size = (int64_t)d.chunk_size;
+    c->enable_priority = d.enable_priority;
+    c->enable_preemption = d.enable_preemption;
+    c->reschedule_partial_prefill = 0;
+    c->enable_prefix_caching = 0;
+}
+nvllm_scheduler *nvllm_scheduler_new(const nvllm_scheduler_config *c, int64_t block_size,
+                                     int64_t num_blocks) {
+    if (!c || block_size <= 0 || num_blocks < 0 || c->max_num_seqs < 0 || c->max_prefill_tokens < 0 ||
+        c->chunk_size < 0) {
+        set_last_error(ErrorKind::Config, "Scheduler: bad configuration");
+        return nullptr;
+    }
+    core::SchedulerConfig k;
+    k.max_num_seqs = (std::size_t)c->max_num_seqs;
+    k.max_prefill_tokens = (std::size_t)c->max_prefill_tokens;
+    k.enable_chunked_prefill = c->enable_chunked_prefill != 0;
+    k.chunk_size = (std::size_t)c->chunk_size;
+    k.enable_priority = c->enable_priority != 0;
+    k.enable_preemption = c->enable_preemption != 0;
+    k.reschedule_partial_prefill = c->reschedule_partial_prefill != 0;
+    k.enable_prefix_caching = c->enable_prefix_caching != 0;
+    return new (std::nothrow) nvllm_scheduler(k, (std::size_t)block_size, (std::size_t)num_blocks);
+}
+void nvllm_scheduler_free(nvllm_scheduler *s) { delete s; }
+int nvllm_scheduler_add_sequence(nvllm_scheduler *s, uint64_t seq_id, const uint32_t *prompt,
+                                 int64_t num_tokens, int32_t priority) {
+    if (!s || (num_tokens > 0 && !prompt)) return fail(ErrorKind::Null, "scheduler: null pointer");
+    if (num_tokens < 0) return fail(ErrorKind::Config, "scheduler: negative prompt length");
+    s->sched.add_sequence(core::Sequence(seq_id, std::vector<uint32_t>(prompt, prompt + num_tokens), priority));
+    return NVLLM_OK;
+}
+int nvllm_scheduler_remove_sequence(nvllm_scheduler *s, uint64_t seq_id) {
+    return s->sched.remove_sequence(seq_id).has_value() ? 1 : 0;
+}
+int nvllm_scheduler_schedule(nvllm_scheduler *s) {
+    if (!s) return fail(ErrorKind::Null, "scheduler: null handle");
+    s->out = s->sched.schedule();
+    s->out_chunk_sizes.clear();
+    for (uint64_t id : s->out.prefill_sequences) {
+        const auto it = s->out.prefill_chunk_sizes.find(id);
+        s->out_chunk_sizes.push_back(it == s->out.prefill_chunk_sizes.end() ? 0 : (int64_t)it->second);
+    }
+    return NVLLM_OK;
+}
+int64_t nvllm_scheduler_out_num_prefill(const nvllm_scheduler *s) { return (int64_t)s->out.prefill_sequences.size(); }
+int64_t nvllm_scheduler_out_num_decode(const nvllm_scheduler *s) { return (int64_t)s->out.decode_sequences.size(); }
+int64_t nvllm_scheduler_out_num_preempted(const nvllm_scheduler *s) { return (int64_t)s->out.preempted_sequences.size(); }
+const uint64_t *nvllm_scheduler_out_prefill_ids(const nvllm_scheduler *s) { return s->out.prefill_sequences.data(); }
+const uint64_t *nvllm_scheduler_out_decode_ids(const nvllm_scheduler *s) { return s->out.decode_sequences.data(); }
+const uint64_t *nvllm_scheduler_out_preempted_ids(const nvllm_scheduler *s) { return s->out.preempted_sequences.data(); }
+const int64_t *nvllm_scheduler_out_prefill_chunk_sizes(const nvllm_scheduler *s) { return s->out_chunk_sizes.data(); }
+int64_t nvllm_scheduler_out_num_prefill_tokens(const nvllm_scheduler *s) { return (int64_t)s->out.num_prefill_tokens; }
+int64_t nvllm_scheduler_out_num_decode_tokens(const nvllm_scheduler *s) { return (int64_t)s->out.num_decode_tokens; }
+void nvllm_scheduler_finish_sequence(nvllm_scheduler *s, uint64_t seq_id, int reason) {
+    s->sched.finish_sequence(seq_id, static_cast<core::FinishReason>(reason));
+}
+int nvllm_scheduler_append_token(nvllm_scheduler *s, uint64_t seq_id, uint32_t token) {
+    if (!s->sched.append_token(seq_id, token))  // batch.rs:446
+        return fail(ErrorKind::Config, "Sequence " + std::to_string(seq_id) + " not found");
+    return NVLLM_OK;
+}
+int nvllm_scheduler_mark_prefilled(nvllm_scheduler *s, uint64_t seq_id, int64_t num_tokens) {
+    if (num_tokens < 0) return fail(ErrorKind::Config, "scheduler: negative token count");
+    if (!s->sched.mark_prefilled(seq_id, (std::size_t)num_tokens))  // batch.rs:456
+        return fail(ErrorKind::Config, "Sequence " + std::to_string(seq_id) + " not found");
+    return NVLLM_OK;
+}
+int64_t nvllm_scheduler_num_waiting(const nvllm_scheduler *s) { return (int64_t)s->sched.num_waiting(); }
+int64_t nvllm_scheduler_num_running(const nvllm_scheduler *s) { return (int64_t)s->sched.num_running(); }
+int64_t nvllm_scheduler_num_swapped(const nvllm_scheduler *s) { return (int64_t)s->sched.num_swapped(); }
+int nvllm_scheduler_has_unfinished_sequences(const nvllm_scheduler *s) { return s->sched.has_unfinished_sequences(); }
+int nvllm_scheduler_has_pending_requests(const nvllm_scheduler *s) { return s->sched.has_pending_requests(); }
+int64_t nvllm_scheduler_running_sequence_ids(const nvllm_scheduler *s, uint64_t *out, int64_t cap) {
+    const auto &ids = s->sched.running_sequence_ids();
+    for (int64_t i = 0; i < (int64_t)ids.size() && i < cap; ++i) out[i] = ids[(std::size_t)i];
+    return (int64_t)ids.size();
+}
+void nvllm_scheduler_reset(nvllm_scheduler *s) {
+    s->sched.reset();
+    s->out = core::SchedulerOutputs();
+    s->out_chunk_sizes.clear();
+}
+int nvllm_scheduler_seq_status(const nvllm_scheduler *s, uint64_t seq_id) {
+    const core::Sequence *q = s->sched.get_sequence(seq_id);
+    return q ? static_cast<int>(q->status()) : -1;
+}
+int nvllm_scheduler_seq_set_status(nvllm_scheduler *s, uint64_t seq_id, int status) {
+    core::Sequence *q = s->sched.get_sequence_mut(seq_id);
+    if (!q) return fail(ErrorKind::Config, "Sequence " + std::to_string(seq_id) + " not found");
+    static const char *names[] = {"Waiting", "Running", "Swapped", "Finished"};
+    const int from = static_cast<int>(q->status());
+    bool ok = false;
+    switch (status) {
+        case 0: ok = q->set_waiting(); break;
+        case 1: ok = q->set_running(); break;
+        case 2: ok = q->set_swapped(); break;
+        default: return fail(ErrorKind::Config, "seq_set_status: use finish_sequence to finish");
+    }
+    if (!ok)  // Error::InvalidStateTransition (src/error.rs, sequence.rs:254-301)
+        return fail(ErrorKind::Config, std::string("Invalid state transition from ") + names[from] +
+                                           " to " + names[status]);
+    return NVLLM_OK;
+}
+int nvllm_scheduler_seq_finish_reason(const nvllm_scheduler *s, uint64_t seq_id) {
+    const core::Sequence *q = s->sched.get_sequence(seq_id);
+    return q ? static_cast<int>(q->finish_reason()) : -1;
+}
+int64_t nvllm_scheduler_seq_info(const nvllm_scheduler *s, uint64_t seq_id, int what) {
+    const core::Sequence *q = s->sched.get_sequence(seq_id);
+    if (!q) return -1;
+    switch (what) {
+        case 0: return (int64_t)q->prompt_len();
+        case 1: return (int64_t)q->output_len();
+        case 2: return (int64_t)q->total_len();
+        case 3: return (int64_t)q->num_prefilled_tokens();
+        case 4: return (int64_t)q->num_tokens_to_prefill();
+        case 5: return q->is_prefill_complete() ? 1 : 0;
+        case 6: return (int64_t)q->block_table().num_blocks();
+        case 7: return (int64_t)q->priority();
+        case 8: return q->last_token_id() ? (int64_t)*q->last_token_id() : -1;
+        default: return -1;
+    }
+}
+int64_t nvllm_scheduler_seq_block_ids(const nvllm_scheduler *s, uint64_t seq_id, int64_t *out, int64_t cap) {
+    const core::Sequence *q = s->sched.get_sequence(seq_id);
+    if (!q) return -1;
+    const auto &ids = q->block_table().get_physical_block_ids();
+    for (int64_t i = 0; i < (int64_t)ids.size() && i < cap; ++i) out[i] = (int64_t)ids[(std::size_t)i];
+    return (int64_t)ids.size();
+}
+int64_t nvllm_scheduler_seq_output_tokens(const nvllm_scheduler *s, uint64_t seq_id, uint32_t *out, int64_t cap) {
+    const core::Sequence *q = s->sched.get_sequence(seq_id);
+    if (!q) return -1;
+    const auto &t = q->output_token_ids();
+    for (int64_t i = 0; i < (int64_t)t.size() && i < cap; ++i) out[i] = t[(std::size_t)i];
+    return (int64_t)t.size();
+}
+int64_t nvllm_scheduler_num_free_blocks(const nvllm_scheduler *s) { return (int64_t)s->sched.block_manager().num_free_blocks(); }
+int64_t nvllm_scheduler_num_used_blocks(const nvllm_scheduler *s) { return (int64_t)s->sched.block_manager().num_used_blocks(); }
+int64_t nvllm_scheduler_num_cached_prefixes(const nvllm_scheduler *s) { return (int64_t)s->sched.block_manager().num_cached_prefixes(); }
+int64_t nvllm_scheduler_block_ref_count(const nvllm_scheduler *s, int64_t block_id) {
+    const core::Block *b = block_id < 0 ? nullptr : s->sched.block_manager().get_block((std::size_t)block_id);
+    return b ? (int64_t)b->ref_count() : -1;
+}
+int nvllm_scheduler_fill_decode_batch(const nvllm_scheduler *s, nvllm_batch *batch) {
+    if (!s || !batch) return fail(ErrorKind::Null, "scheduler: null handle");
+    const nvllm::Error e = s->sched.fill_decode_batch(s->out, &batch->meta);
+    if (!e.ok()) return fail(e.kind, e.message);
+    return NVLLM_OK;
+}
+int64_t nvllm_scheduler_fill_prefill_batch(const nvllm_scheduler *s, int64_t num_new_tokens,
+                                           nvllm_batch *batch, uint64_t *ids_out, int64_t cap) {
+    if (!s || !batch) return fail(ErrorKind::Null, "scheduler: null handle");
+    if (num_new_tokens <= 0) return fail(ErrorKind::Config, "scheduler: chunk length must be positive");
+    std::vector<core::SequenceId> added;
+    const nvllm::Error e = s->sched.fill_prefill_batch(s->out, (std::size_t)num_new_tokens, &batch->meta, &added);
+    if (!e.ok()) return fail(e.kind, e.message);
+    for (int64_t i = 0; i < (int64_t)added.size() && ids_out && i < cap; ++i) ids_out[i] = added[(std::size_t)i];
+    return (int64_t)added.size();
 }
 
 nvllm_block_manager *nvllm_block_manager_new(int64_t num_blocks, int64_t block_size) {

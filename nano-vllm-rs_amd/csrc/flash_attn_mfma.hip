@@ -45,6 +45,12 @@
 
 #include "nvllm_kernels.hpp"
 
+typedef __attribute__((ext_vector_type(4))) int nvllm_i32x4;
+// indexed ("idxen") buffer load: address = base + index * stride; hipcc has no builtin for it
+__device__ nvllm_i32x4 nvllm_struct_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex,
+                                                     int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
+
 namespace nvllm {
 namespace kernels {
 
@@ -57,11 +63,6 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-// indexed ("idxen") buffer load: address = base + index * stride; hipcc has no builtin for it
-__device__ i32x4 struct_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset,
-                                         int soffset, int aux)
-    __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
 
 constexpr int kD = 128;
 constexpr int kWaves = 4;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
                 pg_idx[j] = (4 * t + j >= pg_blk_lim) ? 0xffffffffu : idx;
             }
-            st[j] = __builtin_bit_cast(u32x4, struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
+            st[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
                                                                       (int)pg_idx[j & 3], 0, 0, 0));
         } else {
             const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
