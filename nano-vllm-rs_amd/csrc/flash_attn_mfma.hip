@@ -227,14 +227,21 @@ __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3
 // bottom-right aligned: query row i sits at position Skv - Sq + i (paged.rs:357-381).  The kernel
 // then tiles the query POSITIONS, from the largest multiple of 32 below the first one, so that a
 // 32-row block's diagonal stays inside one 64-key tile exactly as in the top-left case.
-template <bool CAUSAL, bool PAGED>
+// KSPLIT (paged only) = blockIdx.z cuts every workgroup's key walk into gridDim.z equal parts, for
+// launches with fewer workgroups than CUs (one 512-token chunk against a long context is 64 of
+// them): part p walks key tiles [p*n/P, (p+1)*n/P) of its unit's n and leaves a normalised partial
+// (bf16 O; f32 m, l) in the workspace; flash_attn_ksplit_merge_kernel combines the P parts.
+constexpr int kSplitSlotBytes = 2 * kQTile * kD * 2 + 2 * kQTile * 2 * 4;  // 256 rows: O + (m, l)
+
+template <bool CAUSAL, bool PAGED, bool KSPLIT>
 __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
     __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv, int Hq, int Hkv,
     int num_q_tiles, int pair_adjacent, float scale_log2e,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
-    int max_blocks_per_seq, unsigned num_cache_chunks) {
+    int max_blocks_per_seq, unsigned num_cache_chunks, unsigned char *__restrict__ split_ws) {
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
+    static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
 
     const int tid = threadIdx.x;
@@ -307,6 +314,17 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const int d = last < 0 ? 0 : last / kKV + 1;
         nsteps = d < nsteps ? d : nsteps;
     }
+    int tile0 = 0;  // KSPLIT: first key tile of this part
+    if constexpr (KSPLIT) {
+        const int parts = (int)gridDim.z, part = (int)blockIdx.z;
+        tile0 = (int)((long long)part * nsteps / parts);
+        const int k1 = (int)((long long)(part + 1) * nsteps / parts);
+        nA = (nA < k1 ? nA : k1) - tile0;
+        nB = (nB < k1 ? nB : k1) - tile0;
+        nA = nA > 0 ? nA : 0;
+        nB = nB > 0 ? nB : 0;
+        nsteps = k1 - tile0;
+    }
     // a block with rows to store may have no keys at all (PAGED, context shorter than the chunk)
     const bool liveA = rowA0 - pos_shift < Sq;
     const bool liveB = tile_short != tile_long && rowB0 - pos_shift < Sq;
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         if constexpr (PAGED) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                pg_id[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * t, 0);
+                pg_id[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * (t + tile0), 0);
         }
     };
     // fetch piece j of key tile t
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
                 asm("v_mad_u32_u24 %0, %1, %2, %3"
                     : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
-                pg_idx[j] = (4 * t + j >= pg_blk_lim) ? 0xffffffffu : idx;
+                pg_idx[j] = (4 * (t + tile0) + j >= pg_blk_lim) ? 0xffffffffu : idx;
             }
             st[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
                                                                       (int)pg_idx[j & 3], 0, 0, 0));
@@ -818,7 +836,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto final_step = [&](Item &cur) {
         stage_step();
         drain(cur, A, kA, vs_prev);
-        last_item(cur, A, kA, ks_cur, vs_cur, t * kKV);
+        last_item(cur, A, kA, ks_cur, vs_cur, (t + tile0) * kKV);
         K1_STAMP(8);
         step_end();
     };
@@ -870,9 +888,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         stage_step();
         drain(I1, A, kA, vs_prev);
         drain(J1, B, kB, vs_prev);
-        last_item(J1, B, kB, ks_cur, vs_cur, t * kKV);
+        last_item(J1, B, kB, ks_cur, vs_cur, (t + tile0) * kKV);
         if (t == nA - 1) {
-            last_item(I1, A, kA, ks_cur, vs_cur, t * kKV);
+            last_item(I1, A, kA, ks_cur, vs_cur, (t + tile0) * kKV);
         } else if ((nA - 2 - t) & 1) {
             start_item(I0, A, kA, ks_cur);
         } else {
@@ -919,8 +937,35 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             ov[r] = agpr_read<64 * bi + r>();
         });
         const int row = blk.qrow - kv_off;
-        if (live && row >= 0 && row < Sq) {
-            const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        if constexpr (KSPLIT) {
+            // this part's share of the rows: normalised O in bf16, then (m in the exp2 domain, l);
+            // a block without keys in the part carries l = 0 and drops out of the merge
+            if (live) {
+                const int vr = blk.qrow - pos_base;  // row inside the sequence's tiling
+                const int tile = vr / kQTile;
+                const int ur = ((tile == tile_long && tile_long != tile_short) ? kQTile : 0) + (vr & (kQTile - 1));
+                const size_t pairs_max = gridDim.x / (unsigned)Hq;
+                unsigned char *slot = split_ws + ((((size_t)b * Hq + hq) * pairs_max + J) * gridDim.z + blockIdx.z) *
+                                                     (size_t)kSplitSlotBytes;
+                __bf16 *op = reinterpret_cast<__bf16 *>(slot) + ur * kD + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float *a4 = ov + 16 * dt + 4 * i;
+                        u32x2 w;
+                        w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
+                        w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
+                        *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
+                    }
+                if (h == 0) {
+                    float *ml = reinterpret_cast<float *>(slot + 2 * kQTile * kD * 2) + 2 * ur;
+                    ml[0] = blk.m * scale_log2e;
+                    ml[1] = l;
+                }
+            }
+        } else if (live && row >= 0 && row < Sq) {
             __bf16 *op = o + (((int64_t)b * Sq + row) * Hq + hq) * kD + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -939,6 +984,62 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     };
     store(A, kA, liveA);
     store(B, kB, liveB);
+}
+
+// Combines the P partials of every row (KSPLIT): grid = (16, pairs_max * Hq, num_seqs), 16 rows of
+// a unit per workgroup, 16 lanes x 16 bytes per row.  Tile geometry as in the kernel above.
+__global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
+    const unsigned char *__restrict__ ws, __bf16 *__restrict__ o,
+    const int32_t *__restrict__ context_lens, int Sq, int Hq, int max_blocks_per_seq,
+    int pair_adjacent, int parts) {
+    const int b = blockIdx.z;
+    const int hq = blockIdx.y % Hq, J = blockIdx.y / Hq;
+    const int pairs_max = gridDim.y / Hq;
+    int Skv = context_lens[b];
+    const int cap = max_blocks_per_seq * 16;
+    Skv = Skv < 0 ? 0 : (Skv > cap ? cap : Skv);
+    const int kv_off = Skv - Sq;
+    const int pos_shift = kv_off & 31;
+    const int num_q_tiles = (Sq + pos_shift + kQTile - 1) / kQTile;
+    const int pairs = (num_q_tiles + 1) / 2;
+    if (J >= pairs) return;
+    int tile_long = num_q_tiles - 1 - J, tile_short = J;
+    if (pair_adjacent) {
+        const int jr = pairs - 1 - J;
+        tile_short = 2 * jr;
+        tile_long = 2 * jr + 1 < num_q_tiles ? 2 * jr + 1 : 2 * jr;
+    }
+    const int ur = (blockIdx.x << 4) + (threadIdx.x >> 4);
+    const int ch = threadIdx.x & 15;
+    if (ur >= kQTile && tile_long == tile_short) return;
+    const int row = (ur >= kQTile ? tile_long : tile_short) * kQTile + (ur & (kQTile - 1)) - pos_shift;
+    if (row < 0 || row >= Sq) return;
+    const unsigned char *slot0 = ws + (((size_t)b * Hq + hq) * pairs_max + J) * parts * (size_t)kSplitSlotBytes;
+    float mmax = -INFINITY;
+    for (int p = 0; p < parts; ++p) {
+        const float *ml = reinterpret_cast<const float *>(slot0 + (size_t)p * kSplitSlotBytes + 2 * kQTile * kD * 2) + 2 * ur;
+        if (ml[1] > 0.0f) mmax = fmaxf(mmax, ml[0]);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float den = 0.0f;
+    for (int p = 0; p < parts; ++p) {
+        const unsigned char *slot = slot0 + (size_t)p * kSplitSlotBytes;
+        const float *ml = reinterpret_cast<const float *>(slot + 2 * kQTile * kD * 2) + 2 * ur;
+        if (!(ml[1] > 0.0f)) continue;
+        const float w = ml[1] * fast_exp2(ml[0] - mmax);
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(slot + ((size_t)ur * kD + 8 * ch) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += w * __builtin_bit_cast(float, x[i] << 16);
+            acc[2 * i + 1] += w * __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        }
+        den += w;
+    }
+    const float inv = den > 0.0f ? 1.0f / den : 0.0f;
+    u32x4 y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+    *reinterpret_cast<u32x4 *>(o + (((int64_t)b * Sq + row) * Hq + hq) * kD + 8 * ch) = y;
 }
 
 }  // namespace
@@ -980,13 +1081,13 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     auto v = static_cast<const __bf16 *>(a.v);
     auto o = static_cast<__bf16 *>(a.o);
     if (a.causal)
-        flash_attn_mfma_kernel<true, false><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<true, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr);
     else
-        flash_attn_mfma_kernel<false, false><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<false, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr);
     return hipGetLastError();
 }
 
@@ -1007,20 +1108,66 @@ bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a) {
     return al(a.q) && al(a.k_cache) && al(a.v_cache) && al(a.out);
 }
 
+namespace {
+// Key-split factor of a paged launch: enough parts to put about one workgroup on every CU, at
+// least 8 key tiles (512 keys) per part by the longest context the tables allow, at most 8.
+int paged_ksplit_parts(const PagedAttnArgs &a, int pairs) {
+    if (const char *e = getenv("NVLLM_K1_KSPLIT")) {
+        const int v = atoi(e);
+        if (v >= 1) return v > 16 ? 16 : v;
+    }
+    const long long units = (long long)pairs * a.num_heads * a.num_seqs;
+    const long long cus = device_cus();
+    if (units * 2 > cus) return 1;
+    long long parts = cus / units;
+    const long long max_steps = ((long long)a.max_blocks_per_seq * 16 + kKV - 1) / kKV;
+    if (parts > max_steps / 8) parts = max_steps / 8;
+    if (parts > 8) parts = 8;
+    return parts < 1 ? 1 : (int)parts;
+}
+}  // namespace
+
+size_t flash_attn_paged_workspace_bytes(const PagedAttnArgs &a) {
+    const int num_q_tiles = (a.num_new_tokens + 31 + kQTile - 1) / kQTile;
+    const int pairs = (num_q_tiles + 1) / 2;
+    const int parts = paged_ksplit_parts(a, pairs);
+    if (parts <= 1) return 0;
+    return (size_t)a.num_seqs * a.num_heads * pairs * parts * kSplitSlotBytes;
+}
+
 hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     // query positions are tiled from a multiple of 32: up to 31 dead rows in front of a sequence
     const int num_q_tiles = (a.num_new_tokens + 31 + kQTile - 1) / kQTile;
     const int pairs = (num_q_tiles + 1) / 2;
     int pair_adjacent = (int64_t)pairs * a.num_heads * a.num_seqs >= (int64_t)2 * device_cus();
     if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
-    const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs), block(64 * kWaves);
+    const dim3 block(64 * kWaves);
     const float scale_log2e = a.scale * 1.4426950408889634f;
     const unsigned chunks = (unsigned)(a.num_cache_blocks * 16 * a.num_kv_heads * 16);
-    flash_attn_mfma_kernel<true, true><<<grid, block, 0, stream>>>(
-        static_cast<const __bf16 *>(a.q), static_cast<const __bf16 *>(a.k_cache),
-        static_cast<const __bf16 *>(a.v_cache), static_cast<__bf16 *>(a.out), nullptr,
-        a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles, pair_adjacent, scale_log2e,
-        a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks);
+    auto q = static_cast<const __bf16 *>(a.q);
+    auto kc = static_cast<const __bf16 *>(a.k_cache);
+    auto vc = static_cast<const __bf16 *>(a.v_cache);
+    auto o = static_cast<__bf16 *>(a.out);
+    const int parts = paged_ksplit_parts(a, pairs);
+    const size_t need = (size_t)a.num_seqs * a.num_heads * pairs * parts * kSplitSlotBytes;
+    if (parts > 1 && a.workspace && a.workspace_bytes >= need &&
+        (reinterpret_cast<uintptr_t>(a.workspace) & 15u) == 0) {
+        auto ws = static_cast<unsigned char *>(a.workspace);
+        const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs, (unsigned)parts);
+        flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(
+            q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles,
+            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, ws);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+        const dim3 mgrid(16, (unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs);
+        flash_attn_ksplit_merge_kernel<<<mgrid, dim3(256), 0, stream>>>(
+            ws, o, a.context_lens, a.num_new_tokens, a.num_heads, a.max_blocks_per_seq, pair_adjacent, parts);
+        return hipGetLastError();
+    }
+    const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs);
+    flash_attn_mfma_kernel<true, true, false><<<grid, block, 0, stream>>>(
+        q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles,
+        pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, nullptr);
     return hipGetLastError();
 }
 

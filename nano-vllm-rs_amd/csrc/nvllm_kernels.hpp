@@ -76,6 +76,7 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
 // rows per kv head; launch_paged_attn dispatches to it
 bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a);
 hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream);
+size_t flash_attn_paged_workspace_bytes(const PagedAttnArgs &a);  // key-split partials (0 = none)
 
 // K1: flash_attn.hip
 struct FlashAttnArgs {

@@ -579,7 +579,20 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
 
 size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
                                   int max_blocks_per_seq) {
-    if (!paged_attn_fast_path(DType::BF16, T, Hq, Hkv, D, block_size)) return 0;
+    if (!paged_attn_fast_path(DType::BF16, T, Hq, Hkv, D, block_size)) {
+        // more than 32 query rows per kv head: the prefill kernel over the cache, which splits the
+        // key walk of a small launch and needs room for the partials
+        if (D == kD && block_size == kBS && Hkv > 0 && Hq % Hkv == 0 && T > 0 && num_seqs > 0) {
+            PagedAttnArgs a{};
+            a.num_seqs = num_seqs;
+            a.num_new_tokens = T;
+            a.num_heads = Hq;
+            a.num_kv_heads = Hkv;
+            a.max_blocks_per_seq = max_blocks_per_seq;
+            return flash_attn_paged_workspace_bytes(a);
+        }
+        return 0;
+    }
     const int splits = paged_attn_num_splits(num_seqs, Hkv, max_blocks_per_seq);
     if (splits <= 1) return 0;
     const size_t rows = (size_t)num_seqs * T * Hq * splits;

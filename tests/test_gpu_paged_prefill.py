@@ -152,3 +152,48 @@ def test_paged_chunk_equals_contiguous_prefill(dev, S, T):
     if T == S:
         assert torch.equal(paged, want)
     assert_attention_close(paged.float().cpu().numpy(), want.float().cpu().numpy())
+
+
+# ---- key split of small launches (KSPLIT parts + merge kernel) -------------------------------
+@pytest.mark.parametrize("parts", [2, 3, 4, 8])
+@pytest.mark.parametrize("T", [40, 130, 300])
+def test_key_split_matches_oracle(dev, monkeypatch, parts, T):
+    # forced part counts, contexts short enough that some parts are empty, alignments that put
+    # dead rows in front, both tile pairings
+    monkeypatch.setenv("NVLLM_K1_KSPLIT", str(parts))
+    Hq, Hkv, D, bs = 32, 8, 128, 16
+    rng = np.random.default_rng(900 + parts * 10 + T)
+    ctx_lens = [T, T + 1, T + 47, T + 64, T + 333, T + 1000]
+    kc, vc, tables = make_paged_case(rng, ctx_lens, 520, bs, Hkv, D, slack_blocks=1)
+    q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
+    scale = 1.0 / math.sqrt(D)
+    got = _run(dev, q, kc, vc, tables, ctx_lens, scale, fill=-1)
+    want = oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, scale)
+    assert_attention_close(got, want)
+    monkeypatch.setenv("NVLLM_K1_PAIRING", "a")
+    got = _run(dev, q, kc, vc, tables, ctx_lens, scale, fill=-1)
+    assert_attention_close(got, want)
+
+
+def test_key_split_is_chosen_for_one_long_chunk_and_matches_the_plain_launch(dev, monkeypatch):
+    # one 512-token chunk against 4096 cached keys: 64 workgroups unsplit -> 4 parts by default
+    Hq, Hkv, D, bs, T, S = 32, 8, 128, 16, 512, 4096
+    L = nv.capi.lib()
+    assert L.nvllm_paged_attn_workspace_bytes(1, T, Hq, Hkv, D, bs, S // bs) > 0
+    assert L.nvllm_paged_attn_workspace_bytes(16, T, Hq, Hkv, D, bs, S // bs) == 0     # enough workgroups
+    assert L.nvllm_paged_attn_workspace_bytes(1, T, Hq, Hkv, D, bs, 8) == 0             # too few keys
+    g = torch.Generator(device="cpu").manual_seed(3)
+    nb = S // bs + 20
+    kc = torch.randn((nb, bs, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    vc = torch.randn((nb, bs, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    q = torch.randn((1, T, Hq, D), generator=g).to(dev, torch.bfloat16)
+    bt = torch.randperm(nb, generator=g)[:S // bs].to(torch.int32).reshape(1, -1).to(dev)
+    cl = torch.tensor([S - 5], dtype=torch.int32, device=dev)
+    scale = 1 / math.sqrt(D)
+    split = nv.paged_attention_batched(q, kc, vc, bt, cl, scale).float()
+    monkeypatch.setenv("NVLLM_K1_KSPLIT", "1")
+    plain = nv.paged_attention_batched(q, kc, vc, bt, cl, scale).float()
+    torch.cuda.synchronize()
+    d = (split - plain).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-3
+    assert not torch.equal(split, plain)      # the split path really ran
