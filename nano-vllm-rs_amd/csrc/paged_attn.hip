@@ -412,8 +412,9 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     }
 }
 
-// K2b: combine split-K partials.  One wave per output row (seq, t, head);
-// lane owns d = 2*lane, 2*lane+1.
+// K2b: combine split-K partials.  One wave per output row (seq, t, head).  The (m, l) pairs of
+// the row's splits (at most 64, paged_attn_num_splits) are read one per lane and reduced across
+// the wave; then lane owns d = 2*lane, 2*lane+1 and walks the splits with independent loads.
 __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float *__restrict__ ws_o,
                                                                const float *__restrict__ ws_ml,
                                                                __bf16 *__restrict__ out,
@@ -421,15 +422,24 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float *__re
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= num_rows) return;
-    float m = -INFINITY;
-    for (int s = 0; s < num_splits; ++s) m = fmaxf(m, ws_ml[2 * (row * num_splits + s)]);
-    float L = 0.0f, o0 = 0.0f, o1 = 0.0f;
+    float ms = -INFINITY, ls = 0.0f;
+    if (lane < num_splits) {
+        const float2 x = *reinterpret_cast<const float2 *>(ws_ml + 2 * (row * num_splits + lane));
+        ms = x.x;
+        ls = x.y;
+    }
+    float m = ms;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float w_lane = (ms == -INFINITY) ? 0.0f : fast_exp2(ms - m);
+    float L = ls * w_lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) L += __shfl_xor(L, off);
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll 8
     for (int s = 0; s < num_splits; ++s) {
-        const int64_t pr = row * num_splits + s;
-        const float ms = ws_ml[2 * pr], ls = ws_ml[2 * pr + 1];
-        const float w = (ms == -INFINITY) ? 0.0f : fast_exp2(ms - m);
-        L += ls * w;
-        const float2 o = *reinterpret_cast<const float2 *>(ws_o + pr * kD + 2 * lane);
+        const float w = __shfl(w_lane, s);
+        const float2 o = *reinterpret_cast<const float2 *>(ws_o + (row * num_splits + s) * kD + 2 * lane);
         o0 += o.x * w;
         o1 += o.y * w;
     }
@@ -563,14 +573,18 @@ bool paged_attn_fast_path(DType dt, int T, int Hq, int Hkv, int D, int block_siz
 
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq) {
     const int forced = env_int("NVLLM_PAGED_SPLITS", 0);
-    int max_splits = max_blocks_per_seq / 16;  // at least 16 blocks (256 tokens) per split
-    if (max_splits < 1) max_splits = 1;
-    if (max_splits > 64) max_splits = 64;
-    if (forced > 0) return forced < max_splits ? forced : max_splits;
     // aim for >= kWaveTarget (sequence, kv head, split) waves: 8 per CU on 256 CUs is one
     // resident 8-wave workgroup per CU, which measured best (config 3 then needs no merge pass)
     const long kWaveTarget = env_int("NVLLM_PAGED_WAVE_TARGET", 2048);
     const long waves = (long)num_seqs * num_kv_heads;
+    // at least 16 blocks (256 tokens) per split; a launch that would stay under a quarter of the
+    // wave target even then (a handful of sequences: latency, not throughput) goes down to 4 blocks
+    int min_blocks = 16;
+    if (waves * (max_blocks_per_seq / 16 > 0 ? max_blocks_per_seq / 16 : 1) < kWaveTarget / 4) min_blocks = 4;
+    int max_splits = max_blocks_per_seq / min_blocks;
+    if (max_splits < 1) max_splits = 1;
+    if (max_splits > 64) max_splits = 64;  // the merge pass walks a row's splits one after the other
+    if (forced > 0) return forced < max_splits ? forced : max_splits;
     long splits = (kWaveTarget + waves - 1) / (waves > 0 ? waves : 1);
     if (splits < 1) splits = 1;
     if (splits > max_splits) splits = max_splits;
@@ -616,8 +630,21 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         const int64_t reach = (int64_t)a.num_seqs * a.max_blocks_per_seq * 2 * kBS * a.num_kv_heads * kRowBytes;
         const bool nt = env_int("NVLLM_PAGED_NT", reach > ((int64_t)256 << 20) ? 1 : 0) != 0;
         const int R = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
+        // kv heads per workgroup: 8 waves sharing a block's rows is the throughput shape; a launch
+        // of fewer workgroups than CUs spreads its heads over more of them instead
         int hpb = env_int("NVLLM_PAGED_HPB", 0);
-        if (hpb != 1 && hpb != 2 && hpb != 4 && hpb != 8) hpb = a.num_kv_heads >= 8 ? 8 : (a.num_kv_heads >= 4 ? 4 : (a.num_kv_heads >= 2 ? 2 : 1));
+        if (hpb != 1 && hpb != 2 && hpb != 4 && hpb != 8) {
+            hpb = a.num_kv_heads >= 8 ? 8 : (a.num_kv_heads >= 4 ? 4 : (a.num_kv_heads >= 2 ? 2 : 1));
+            static int num_cus = 0;
+            if (num_cus == 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                    n = 256;
+                num_cus = n;
+            }
+            while (hpb > 1 && (long)splits * a.num_seqs * ((a.num_kv_heads + hpb - 1) / hpb) < num_cus) hpb /= 2;
+        }
         if (R <= 16) {
             switch (hpb) {
                 case 8: launch_fast<1, 8>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
