@@ -73,6 +73,8 @@ constexpr int kKRow = 272, kKTile = kKV * kKRow;  // 17 KiB, padded rows (confli
 constexpr int kVRing = 3, kKRing = 2;
 constexpr int kKBase = kVRing * kVTile;
 constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 83,968 B
+constexpr int kORow = 272, kOStage = 32 * kORow;  // epilogue: O rows of a block, padded
+static_assert(2 * kWaves * kOStage <= kLdsBytes, "O staging must fit the K/V rings");
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
 
 // Diagnostic build only (scripts/k1_lab, -DNVLLM_K1_STAMPS): per-wave cycle sums of the loop's
@@ -970,8 +972,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     ml[1] = l;
                 }
             }
-        } else if (live && row >= 0 && row < Sq) {
-            __bf16 *op = o + (((int64_t)b * Sq + row) * Hq + hq) * kD + 4 * h;
+        } else {
+            // O goes through a wave-private LDS image (the K/V rings are free after the last
+            // barrier) and leaves as whole 256-byte rows, four per store instruction: stored
+            // straight from the accumulator layout every instruction would touch 32 rows, 16
+            // bytes each
+            unsigned char *stg = lds + (wave * 2 + bi) * kOStage;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -980,8 +986,19 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     u32x2 w;
                     w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
                     w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
-                    *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
+                    *reinterpret_cast<u32x2 *>(stg + c * kORow + (32 * dt + 8 * i + 4 * h) * 2) = w;
                 }
+            const int row0 = blk.qrow - c - kv_off;  // the block's first query row
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int ri = 4 * r + (lane >> 4);
+                const u32x4 x = *reinterpret_cast<const u32x4 *>(stg + ri * kORow + (lane & 15) * 16);
+                const int orow = row0 + ri;
+                if (live && orow >= 0 && orow < Sq)
+                    *reinterpret_cast<u32x4 *>(o + (((int64_t)b * Sq + orow) * Hq + hq) * kD + (lane & 15) * 8) = x;
+            }
+        }
+        if (!KSPLIT && live && row >= 0 && row < Sq) {
             if (lse && h == 0)
                 lse[((int64_t)b * Hq + hq) * Sq + row] =
                     blk.m * scale_log2e * 0.6931471805599453f + logf(l);
