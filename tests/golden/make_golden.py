@@ -125,6 +125,81 @@ def allocator_traces():
                      "reference pins only equality/inequality, so values are best-effort")
 
 
+def norm_rope_cases():
+    """K5: per-head RMSNorm + RoPE on q/k, then K/V into their slots.  bf16 inputs,
+    weights and cos/sin tables (the reference holds them in the model dtype); expected values are
+    the oracle's f32 results before the final rounding."""
+    cases = {}
+    rng = np.random.default_rng(500)
+    for name, n, Hq, Hkv, D, nb, bs, max_pos, theta in [("d128_gqa", 19, 8, 2, 128, 4, 16, 256, 1e6),
+                                                        ("d64_mha", 7, 4, 4, 64, 2, 8, 64, 1e4)]:
+        q, k, v = bf16_randn(rng, (n, Hq, D)), bf16_randn(rng, (n, Hkv, D)), bf16_randn(rng, (n, Hkv, D))
+        qw = oracle.bf16_round(1.0 + 0.25 * bf16_randn(rng, (D,)))
+        kw = oracle.bf16_round(1.0 + 0.25 * bf16_randn(rng, (D,)))
+        pos = rng.integers(0, max_pos, size=n).astype(np.int32)
+        slots = rng.permutation(nb * bs)[:n].astype(np.int64)
+        cos, sin = oracle.rope_cache(D, max_pos, theta)
+        cos, sin = oracle.bf16_round(cos), oracle.bf16_round(sin)
+        qo, ko = np.empty_like(q), np.empty_like(k)
+        for i in range(n):
+            a, b = oracle.qk_norm_rope(q[None, i:i + 1], k[None, i:i + 1], qw, kw, 1e-6, cos, sin, int(pos[i]))
+            qo[i], ko[i] = a[0, 0], b[0, 0]
+        kc0, vc0 = bf16_randn(rng, (nb, bs, Hkv, D)), bf16_randn(rng, (nb, bs, Hkv, D))
+        kc, vc = oracle.write_kv_to_cache(ko[None], v[None], kc0, vc0, slots, bs)
+        cases[name] = dict(q=bits(q), k=bits(k), v=bits(v), qw=bits(qw), kw=bits(kw), pos=pos, slots=slots,
+                           theta=np.float64(theta), max_pos=np.int64(max_pos), eps=np.float64(1e-6),
+                           kc0=bits(kc0), vc0=bits(vc0), q_out=qo, k_out=ko, kc=kc, vc=bits(vc))
+    return cases
+
+
+def scheduler_traces():
+    """Operation traces of the scheduler with every decision the reference's
+    semantics produce: sequence ids per list, chunk sizes, token counts, queue sizes, block ids."""
+    traces = []
+    for seed in (0, 1, 2, 3):
+        rng = np.random.default_rng(600 + seed)
+        cfg = dict(max_num_seqs=int(rng.integers(2, 9)), max_prefill_tokens=int(rng.integers(20, 200)),
+                   enable_chunked_prefill=bool(seed & 1), chunk_size=int(rng.integers(8, 64)),
+                   enable_priority=True, enable_preemption=bool(seed & 2))
+        nb = int(rng.integers(6, 40))
+        s = oracle.SchedulerOracle(block_size=16, num_blocks=nb, **cfg)
+        ops, next_id, live = [], 1, []
+        for _ in range(100):
+            r = rng.random()
+            if r < 0.35:
+                prompt = rng.integers(0, 1000, size=int(rng.integers(1, 90))).tolist()
+                prio = int(rng.integers(-3, 4))
+                s.add_sequence(oracle.SequenceOracle(next_id, prompt, prio))
+                ops.append(["add", next_id, prompt, prio])
+                live.append(next_id)
+                next_id += 1
+            elif r < 0.75:
+                o = s.schedule()
+                for sid in o.prefill_sequences:
+                    s.mark_prefilled(sid, o.prefill_chunk_sizes[sid])
+                for sid in o.decode_sequences:
+                    s.append_token(sid, 7)
+                ops.append(["schedule", dict(prefill=list(o.prefill_sequences), decode=list(o.decode_sequences),
+                                             preempted=list(o.preempted_sequences),
+                                             chunks={str(k): int(v) for k, v in o.prefill_chunk_sizes.items()},
+                                             tokens=[int(o.num_prefill_tokens), int(o.num_decode_tokens)])])
+            elif r < 0.87 and live:
+                sid = live[int(rng.integers(len(live)))]
+                s.finish_sequence(sid, 1)
+                ops.append(["finish", sid])
+            elif live:
+                sid = live.pop(int(rng.integers(len(live))))
+                ops.append(["remove", sid, s.remove_sequence(sid) is not None])
+            else:
+                continue
+            ops[-1].append(dict(queues=[s.num_waiting(), s.num_running(), s.num_swapped()],
+                                used=s.bm.num_used_blocks(), running=list(s.running_ids),
+                                blocks={str(i): list(s.sequences[i].block_ids) for i in live if i in s.sequences}))
+        traces.append(dict(config=cfg, block_size=16, num_blocks=nb, ops=ops))
+    return dict(traces=traces, finish_reason="1 = MaxTokens; every schedule is followed by the engine's "
+                "step: mark_prefilled(chunk) per prefill id, append_token(7) per decode id")
+
+
 def main():
     np.savez_compressed(os.path.join(OUT, "flash.npz"),
                         **{"%s/%s" % (c, k): v for c, d in flash_cases().items() for k, v in d.items()})
@@ -132,9 +207,13 @@ def main():
                         **{"%s/%s" % (c, k): v for c, d in paged_cases().items() for k, v in d.items()})
     np.savez_compressed(os.path.join(OUT, "kv_write.npz"),
                         **{"%s/%s" % (c, k): v for c, d in kv_write_cases().items() for k, v in d.items()})
+    np.savez_compressed(os.path.join(OUT, "norm_rope.npz"),
+                        **{"%s/%s" % (c, k): v for c, d in norm_rope_cases().items() for k, v in d.items()})
     with open(os.path.join(OUT, "allocator.json"), "w") as f:
         json.dump(allocator_traces(), f)
-    for n in ("flash.npz", "paged.npz", "kv_write.npz", "allocator.json"):
+    with open(os.path.join(OUT, "scheduler.json"), "w") as f:
+        json.dump(scheduler_traces(), f)
+    for n in ("flash.npz", "paged.npz", "kv_write.npz", "norm_rope.npz", "allocator.json", "scheduler.json"):
         print(n, os.path.getsize(os.path.join(OUT, n)))
 
 

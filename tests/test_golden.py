@@ -93,6 +93,70 @@ def test_product_allocator_replays_traces_bit_exact():
         assert oracle.hash_token_block(h["tokens"], h["parent"]) == h["hash"]
 
 
+def _norm_rope_tables(c):
+    cos, sin = oracle.rope_cache(c["q"].shape[-1], int(c["max_pos"]), float(c["theta"]))
+    return oracle.bf16_round(cos), oracle.bf16_round(sin)
+
+
+def test_oracle_reproduces_norm_rope_goldens():
+    for name, c in _load("norm_rope.npz").items():
+        q, k, v = _f32(c["q"]), _f32(c["k"]), _f32(c["v"])
+        cos, sin = _norm_rope_tables(c)
+        for i in range(q.shape[0]):
+            a, b = oracle.qk_norm_rope(q[None, i:i + 1], k[None, i:i + 1], _f32(c["qw"]), _f32(c["kw"]),
+                                       float(c["eps"]), cos, sin, int(c["pos"][i]))
+            assert np.array_equal(a[0, 0], c["q_out"][i]) and np.array_equal(b[0, 0], c["k_out"][i]), name
+        bs = c["kc0"].shape[1]
+        kc, vc = oracle.write_kv_to_cache(c["k_out"][None], v[None], _f32(c["kc0"]), _f32(c["vc0"]),
+                                          c["slots"], bs)
+        assert np.array_equal(kc, c["kc"]) and np.array_equal(vc, _f32(c["vc"])), name
+
+
+def _replay_scheduler(tr, make, add, seq_blocks, running, used, remove):
+    s = make(tr)
+    live = []
+    for op in tr["ops"]:
+        kind, state = op[0], op[-1]
+        if kind == "add":
+            add(s, op[1], op[2], op[3])
+            live.append(op[1])
+        elif kind == "schedule":
+            o, want = s.schedule(), op[1]
+            assert list(o.prefill_sequences) == want["prefill"]
+            assert list(o.decode_sequences) == want["decode"]
+            assert list(o.preempted_sequences) == want["preempted"]
+            assert {str(k): int(v) for k, v in o.prefill_chunk_sizes.items()} == want["chunks"]
+            assert [o.num_prefill_tokens, o.num_decode_tokens] == want["tokens"]
+            for sid in o.prefill_sequences:
+                s.mark_prefilled(sid, o.prefill_chunk_sizes[sid])
+            for sid in o.decode_sequences:
+                s.append_token(sid, 7)
+        elif kind == "finish":
+            s.finish_sequence(op[1], 1)
+        else:
+            assert remove(s, op[1]) == op[2]
+            live.remove(op[1])
+        assert [s.num_waiting(), s.num_running(), s.num_swapped()] == state["queues"]
+        assert used(s) == state["used"] and list(running(s)) == state["running"]
+        for sid, blocks in state["blocks"].items():
+            assert seq_blocks(s, int(sid)) == blocks, (kind, sid)
+
+
+def test_oracle_and_product_scheduler_replay_traces_bit_exact():
+    data = json.load(open(os.path.join(G, "scheduler.json")))
+    for tr in data["traces"]:
+        _replay_scheduler(
+            tr, lambda t: oracle.SchedulerOracle(block_size=t["block_size"], num_blocks=t["num_blocks"], **t["config"]),
+            lambda s, i, p, pr: s.add_sequence(oracle.SequenceOracle(i, p, pr)),
+            lambda s, i: list(s.sequences[i].block_ids), lambda s: s.running_ids,
+            lambda s: s.bm.num_used_blocks(), lambda s, i: s.remove_sequence(i) is not None)
+        _replay_scheduler(
+            tr, lambda t: nv.Scheduler(nv.SchedulerConfig(**t["config"]), t["block_size"], t["num_blocks"]),
+            lambda s, i, p, pr: s.add_sequence(i, p, pr),
+            lambda s, i: list(s.get_sequence(i).block_ids()), lambda s: s.running_sequence_ids(),
+            lambda s: s.num_used_blocks(), lambda s, i: bool(s.remove_sequence(i)))
+
+
 # ---------------------------------------------------------------- GPU: kernels via the C ABI
 @pytest.mark.gpu
 def test_gpu_flash_goldens(dev):
@@ -123,3 +187,28 @@ def test_gpu_kv_write_goldens_bit_exact(dev):
                              c["slots"].tolist(), bs)
         torch.cuda.synchronize()
         assert np.array_equal(_bits_host(kc), c["kc"]) and np.array_equal(_bits_host(vc), c["vc"]), name
+
+
+@pytest.mark.gpu
+def test_gpu_norm_rope_goldens(dev):
+    """K5 through the C ABI: q/k within one bf16 ulp of the golden f32 values (the kernel rounds
+    once), V and untouched slots of both caches bit-exact."""
+    for name, c in _load("norm_rope.npz").items():
+        D = c["q"].shape[-1]
+        rot = nv.RotaryEmbedding(D, int(c["max_pos"]), float(c["theta"]), torch.bfloat16, dev)
+        kc, vc = _bf16_dev(c["kc0"], dev), _bf16_dev(c["vc0"], dev)
+        k_out = torch.empty(c["k"].shape, dtype=torch.bfloat16, device=dev)
+        q_out = nv.qk_norm_rope_cache(_bf16_dev(c["q"], dev), _bf16_dev(c["k"], dev), _bf16_dev(c["v"], dev),
+                                      _bf16_dev(c["qw"], dev), _bf16_dev(c["kw"], dev), float(c["eps"]), rot,
+                                      torch.from_numpy(c["pos"]).to(dev), kc, vc,
+                                      torch.from_numpy(c["slots"]).to(dev), k_out=k_out)
+        torch.cuda.synchronize()
+        for got, want in ((q_out, c["q_out"]), (k_out, c["k_out"]), (kc, c["kc"])):
+            got = got.float().cpu().numpy()
+            assert np.all(np.abs(got - want) <= (2.0 ** -7) * np.abs(want) + 1e-6), name
+        assert np.array_equal(_bits_host(vc), c["vc"]), name
+        bs = c["kc0"].shape[1]
+        untouched = np.ones(c["kc0"].shape[0] * bs, bool)
+        untouched[c["slots"]] = False
+        kcb = _bits_host(kc).reshape(-1, *c["kc0"].shape[2:])
+        assert np.array_equal(kcb[untouched], c["kc0"].reshape(kcb.shape)[untouched]), name
