@@ -306,13 +306,15 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
 def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
     Hkv, D, bs, nb = 8, 128, 16, 40960
     g = torch.Generator(device="cpu").manual_seed(6 + rank)
-    key = torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)
-    val = torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)
+    nbuf = 4                                   # rotate so the caches do not serve the re-reads
+    bufs = [(torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16),
+             torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)) for _ in range(nbuf)]
     kc = torch.zeros((nb, bs, Hkv, D), dtype=torch.bfloat16, device=dev)
     vc = torch.zeros_like(kc)
     slots = torch.randperm(nb * bs, generator=g)[:num_tokens].to(dev)
 
     def step(i):
+        key, val = bufs[i % nbuf]
         nv.reshape_and_cache(key, val, kc, vc, slots)
 
     wall, ev_ms = timed_loop(step, steps, warmup, world, dev)
@@ -397,7 +399,7 @@ def main():
                            if k in p}
         if "cpu_baseline" in p:
             also["prefill"]["cpu_baseline"] = p["cpu_baseline"]
-        for n in (256, 4096):
+        for n in (256, 4096, 32768):
             w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, n)
             also["kv_write_%d" % n] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
                                            frac=w["roofline"]["frac"])
