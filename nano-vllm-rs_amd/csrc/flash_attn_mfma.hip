@@ -695,13 +695,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         });
     };
 
-    // ---- un-pipelined pieces (a block's last, masked key tile; pipeline drain)
-    auto qk_plain = [&](Item &it, auto bt, int kslot) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) read_k(kslot, j);
-        slot_qk(it, bt, kslot, it, no_valu, no_rd);
-        mfma_fence();
-    };
+    // ---- un-pipelined pieces (pipeline drain) and the mask of a block's last key tile
     auto pv_plain = [&](Item &it, auto bt, int vslot) {
         // P must be complete before the fence below (VALU write -> MFMA operand wait states)
         asm volatile("" : "+v"(it.p[0]), "+v"(it.p[1]), "+v"(it.p[2]), "+v"(it.p[3]));
@@ -739,24 +733,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         rescale(it, bt);
         pv_plain(it, bt, vslot);
     };
-    // a block's last key tile, masked, un-pipelined
-    auto last_item = [&](Item &it, Block &blk, auto bt, int kslot, int vslot, int kv0) {
-        qk_plain(it, bt, kslot);
-        mask(it, blk, kv0);
-        softmax_plain(it, blk, 0);
-        rescale(it, bt);
-        pv_plain(it, bt, vslot);
-    };
-    // an interior tile started un-pipelined: leaves the item pending with kFirst ticks done
-    auto start_item = [&](Item &it, Block &blk, auto bt, int kslot) {
-        qk_plain(it, bt, kslot);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) max_step(it, j);
-        decide(it, blk);
-#pragma unroll
-        for (int n = 0; n < kFirst; ++n) tick(it, n);
-    };
-
     Item I0, I1;    // block A's two score register sets
     Item J0, J1;    // block B's
     // "nothing pending" = an item whose P is all zero, multiplied into a zeroed V slot
@@ -829,13 +805,16 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         for (int j = 0; j < 4; ++j) read_k(ks_cur, j);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // block A alone, interior tile: QK^T into `nxt` while `cur` (pending) is finished and multiplied
-    auto single_step = [&](Item &cur, Item &nxt) {
+    // block A alone: QK^T of tile t into `nxt` while `cur` (pending, tile t-1) is finished and
+    // multiplied.  MASKED (A's last tile): the fresh scores are masked between the two slots, the
+    // rest of the step is the same, and the caller drains `nxt` afterwards.
+    auto single_step = [&](Item &cur, Item &nxt, auto masked) {
         stage_ids(t + 2);
         prime_k();
         slot_qk(nxt, kA, ks_cur, cur, [&](int i) { valu_qk(cur, i); st_w8(i); },
                 [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(5);
+        if constexpr (decltype(masked)::value) mask(nxt, A, (t + tile0) * kKV);
         rescale(cur, kA);
         slot_pv(cur, kA, vs_prev, nxt, [&](int i) { valu_pv(nxt, A, i); st_l8(i); }, no_rd);
         K1_STAMP(6);
@@ -844,17 +823,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #endif
         step_end();
     };
-    auto final_step = [&](Item &cur) {
-        stage_step();
-        drain(cur, A, kA, vs_prev);
-        last_item(cur, A, kA, ks_cur, vs_cur, (t + tile0) * kKV);
-        K1_STAMP(8);
-        step_end();
-    };
 
-    // both blocks, interior tile: QK^T of tile t into (nA_, nB_) while the pending items (pA, pB:
-    // tile t-1) are finished and multiplied
-    auto dual_step = [&](Item &pA, Item &pB, Item &nA_, Item &nB_) {
+    // both blocks: QK^T of tile t into (nA_, nB_) while the pending items (pA, pB: tile t-1) are
+    // finished and multiplied.  MASKED = block B's last tile (and block A's too when mask_a).
+    auto dual_step = [&](Item &pA, Item &pB, Item &nA_, Item &nB_, auto masked, bool mask_a) {
         stage_ids(t + 2);
         prime_k();
         slot_qk2(nA_, nB_, ks_cur, pA, pB,
@@ -866,6 +838,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                  },
                  [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(0);
+        if constexpr (decltype(masked)::value) {
+            mask(nB_, B, (t + tile0) * kKV);
+            if (mask_a) mask(nA_, A, (t + tile0) * kKV);
+        }
         rescale(pA, kA);
         rescale(pB, kB);
         slot_pv2(pA, pB, vs_prev, nA_, nB_,
@@ -883,48 +859,52 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #endif
         step_end();
     };
+    constexpr std::false_type kInterior{};
+    constexpr std::true_type kLastTile{};
 
-    // ---- phase 1: both blocks, interior tiles, alternating the two score register sets; the
-    // (empty) pending items start in whichever set makes the phase end with them in set 1
-    if (nB > 1) {
-        if ((nB - 1) & 1) dual_step(I0, J0, I1, J1);
-        while (t < nB - 1) {
-            dual_step(I1, J1, I0, J0);
-            dual_step(I0, J0, I1, J1);
-        }
-    }
-    // ---- block B's last tile: finish what is pending (set 1), then B and A un-pipelined.  Block A
-    // goes on alone from the set that makes phase 2 end in set 1.
+    // ---- phase 1: both blocks, alternating the two score register sets.  The (empty) pending items
+    // start in whichever set lets block B's last tile go from set 0 to set 1.  That tile is a
+    // pipelined step like the others, only masked; its item is then finished on its own (drain)
+    // during the following step, while its V tile is still in the ring.
     if (nB > 0) {
-        stage_step();
-        drain(I1, A, kA, vs_prev);
+        if ((nB - 1) & 1) dual_step(I1, J1, I0, J0, kInterior, false);
+        while (t < nB - 1) {
+            dual_step(I0, J0, I1, J1, kInterior, false);
+            dual_step(I1, J1, I0, J0, kInterior, false);
+        }
+        const bool a_too = (t == nA - 1);
+        dual_step(I0, J0, I1, J1, kLastTile, a_too);
         drain(J1, B, kB, vs_prev);
-        last_item(J1, B, kB, ks_cur, vs_cur, (t + tile0) * kKV);
-        if (t == nA - 1) {
-            last_item(I1, A, kA, ks_cur, vs_cur, (t + tile0) * kKV);
-        } else if ((nA - 2 - t) & 1) {
-            start_item(I0, A, kA, ks_cur);
-        } else {
-            start_item(I1, A, kA, ks_cur);
-        }
+        if (a_too) drain(I1, A, kA, vs_prev);
         K1_STAMP(7);
-        step_end();
     }
-    // ---- phase 2: block A alone, interior tiles
-    if (t < nA - 1) {
-        if ((nA - 1 - t) & 1) single_step(I0, I1);
-        while (t < nA - 1) {
-            single_step(I1, I0);
-            single_step(I0, I1);
+    // ---- phase 2: block A alone; its pending item is in set 1, the last tile goes from set 0 to
+    // set 1, so an even number of interior tiles in between needs the two sets exchanged (only
+    // happens when a key split cuts the walks; with no block B both sets are empty anyway)
+    if (t < nA) {
+        const int n2 = nA - 1 - t;
+        if (!(n2 & 1) && nB > 0) {
+            const Item x = I0;
+            I0 = I1;
+            I1 = x;
         }
+        if (n2 & 1) single_step(I1, I0, kInterior);
+        while (t < nA - 1) {
+            single_step(I0, I1, kInterior);
+            single_step(I1, I0, kInterior);
+        }
+        single_step(I0, I1, kLastTile);
+        drain(I1, A, kA, vs_prev);
+        K1_STAMP(8);
     }
-    if (t == nA - 1) final_step(I1);
     // ---- steps this wave has no keys for (the workgroup's other waves do)
     while (t < nsteps) {
         stage_step();
         K1_STAMP(9);
         step_end();
     }
+    // a drain after the last step still reads the V ring, which the epilogue reuses for O
+    __syncthreads();
 
 #ifdef NVLLM_K1_STAMPS
     float *lse_dbg = lse;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# correctness + timing of the lab's variants over the shapes that exercise every phase combination
+set -e
+L=./scripts/k1_lab/k1_lab; O=gpurun_out/lab_cmp.txt; : > $O
+for args in "B=1 S=4096" "B=8 S=4096" "B=2 S=1024" "B=1 S=4096 causal=0" "B=1 S=1000" "B=3 S=520 causal=0" "B=1 S=128" "B=2 S=200" "B=1 S=4096 spike=1" "B=4 S=2048 Hq=32 Hkv=8"; do
+  timeout -k 10 100 $L $args rounds=3 >> $O 2>&1
+done
