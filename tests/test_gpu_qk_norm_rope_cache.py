@@ -99,6 +99,24 @@ def test_bf16_fast_path(dev, n, Hq, Hkv):
     assert np.array_equal(gkc.reshape(nb * bs, Hkv, D)[slots], gk)
 
 
+def test_bf16_fast_path_streaming_launch(dev):
+    """>= 2048 tokens: the launch whose outputs leave as non-temporal stores; same bars."""
+    n, Hq, Hkv, D, nb, bs, max_pos, eps = 2100, 8, 2, 128, 140, 16, 5000, 1e-6
+    rng = np.random.default_rng(77)
+    q, k, v, qw, kw, pos, slots, rot, cos, sin = _case(rng, dev, torch.bfloat16, n, Hq, Hkv, D, nb, bs, max_pos)
+    sent = np.full((nb, bs, Hkv, D), 768.0, np.float32)
+    wq, wk, wkc, wvc = _oracle(q, k, v, qw, kw, eps, cos, sin, pos, slots, sent, sent, bs)
+    gq, gk, gkc, gvc = _run(dev, torch.bfloat16, q, k, v, qw, kw, eps, rot, pos, slots, nb, bs)
+    _close_bf16(gq, wq)
+    _close_bf16(gk, wk)
+    _close_bf16(gkc, wkc)
+    assert np.array_equal(gvc, wvc)
+    untouched = np.ones(nb * bs, bool)
+    untouched[slots] = False
+    assert (gkc.reshape(nb * bs, -1)[untouched] == 768.0).all()
+    assert (gvc.reshape(nb * bs, -1)[untouched] == 768.0).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("D", [4, 32, 64, 96, 128, 256])
 def test_generic_path(dev, dtype, D):
