@@ -1,0 +1,30 @@
+"""Multi-token verify on the paged cache: time vs number of new tokens T (256 seqs x 2048 ctx, 32Q/8KV).
+T*G <= 32 rows per kv head runs in the decode kernel, above that in the flash kernel over the cache."""
+import math, os, sys
+import torch
+sys.path.insert(0, '.')
+import nano_vllm_rs_amd as nv
+dev = torch.device('cuda:0')
+Hq, Hkv, D, bs = 32, 8, 128, 16
+N, ctx = int(os.environ.get('SWEEP_N', 256)), int(os.environ.get('SWEEP_CTX', 2048))
+nblk = ctx // bs
+nb = N * nblk
+kc = torch.randn((nb, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
+vc = torch.randn((nb, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
+bt = torch.randperm(nb).to(torch.int32).reshape(N, nblk).to(dev)
+cl = torch.full((N,), ctx, dtype=torch.int32, device=dev)
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+Ts = [int(x) for x in os.environ.get('SWEEP_T', '1,4,8,9,12,13,16,24,32,36,48,64,96').split(',')]
+print('N', N, 'ctx', ctx, 'max_chunks', os.environ.get('NVLLM_PAGED_MAX_CHUNKS'), flush=True)
+for T in Ts:
+    q = torch.randn((N, T, Hq, D), device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: nv.paged_attention_batched(q, kc, vc, bt, cl, 1 / math.sqrt(D)))
+    by = N * ctx * Hkv * D * 2 * 2
+    print('T', T, 'rows/kvhead', T * Hq // Hkv, 'us', round(t, 1), 'GB/s of KV', round(by / t / 1e3, 1), flush=True)

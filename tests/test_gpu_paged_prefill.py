@@ -1,4 +1,4 @@
-"""K1 over the paged cache: chunked prefill / long verify (more than 32 query rows per kv head).
+"""K1 over the paged cache: chunked prefill / long verify (launches the decode kernel does not take: more than 48 query rows per kv head, or more than a few such chunks).
 
 Same contract and oracle as the decode tests (oracle.paged_attention restates reference
 src/attention/paged.rs:117-192; the bottom-right causal mask is paged.rs:357-381): T new tokens
@@ -34,9 +34,9 @@ def _run(dev, q, kc, vc, tables, ctx_lens, scale, max_blocks=None, fill=0):
     return out.float().cpu().numpy()
 
 
-@pytest.mark.parametrize("T", [9, 16, 31, 33, 64, 100, 128, 129, 200, 300])
+@pytest.mark.parametrize("T", [9, 12, 13, 16, 31, 33, 64, 100, 128, 129, 200, 300])
 def test_chunk_lengths_and_alignments(dev, T):
-    Hq, Hkv, D, bs = 32, 8, 128, 16          # G = 4: T >= 9 leaves the decode kernel's 32 rows
+    Hq, Hkv, D, bs = 32, 8, 128, 16          # G = 4: T >= 13 leaves the decode kernel's 48 rows (9 and 12: its third query tile)
     rng = np.random.default_rng(7000 + T)
     ctx_lens = [T + c for c in (0, 1, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 100, 333)]
     kc, vc, tables = make_paged_case(rng, ctx_lens, 420, bs, Hkv, D, slack_blocks=1)
