@@ -140,7 +140,8 @@ struct Block {
 #ifdef K1_DBG_VALU_L
     float l;
 #endif
-    int qrow;  // this lane's query row
+    int qrow;  // this lane's query row (position)
+    int r0;    // first (packed) row of the block in the sequence's tiling
 };
 #define K1_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
 
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv, int Hq, int Hkv,
     int num_q_tiles, int pair_adjacent, float scale_log2e,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
-    int max_blocks_per_seq, unsigned num_cache_chunks, unsigned char *__restrict__ split_ws) {
+    int max_blocks_per_seq, unsigned num_cache_chunks, unsigned char *__restrict__ split_ws,
+    int pack_shift) {
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
@@ -256,14 +258,24 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
 
-    // blockIdx.x = kvh + Hkv * (hg + G * J): kv head fastest
+    // PAGED launches may pack the gp = 2^gsh query heads of a group into the rows: packed row rho
+    // is position rho >> gsh, head rho & (gp - 1) of the group.  A chunk of T tokens then fills
+    // T * gp rows of one kv head's workgroups instead of T rows in each of gp of them, which is what
+    // short chunks need (T = 64 at 32Q/8KV: one full workgroup per kv head, not four with a quarter
+    // of their rows live).  A 32-row block spans 32 / gp positions, so its diagonal still lies in
+    // one 64-key tile.  gsh = 0: a row is a position, as in the dense kernel.
+    const int gsh = PAGED ? pack_shift : 0;
+    const int gp = 1 << gsh;
+    // blockIdx.x = kvh + Hkv * (hg + Gq * J): kv head fastest; Gq head groups of gp heads per kv head
     const int G = Hq / Hkv;
+    const int Gq = G >> gsh;
     int bid = blockIdx.x;
     const int kvh = bid % Hkv;
     bid /= Hkv;
-    const int hg = bid % G;
-    const int J = bid / G;
-    const int hq = kvh * G + hg;
+    const int hg = bid % Gq;
+    const int J = bid / Gq;
+    const int hu = kvh + Hkv * hg;                          // unit (kv head, head group)
+    const int hq = kvh * G + hg * gp + (c & (gp - 1));      // this lane's query head
     const int b = blockIdx.y;
     // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
     // the tiling starts) and the dead rows in front of the first block (pos_shift)
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         kv_off = Skv - Sq;
         pos_shift = kv_off & 31;
         pos_base = kv_off - pos_shift;
-        num_q_tiles = (Sq + pos_shift + kQTile - 1) / kQTile;
+        num_q_tiles = (((Sq + pos_shift) << gsh) + kQTile - 1) / kQTile;
         if (J >= (num_q_tiles + 1) / 2) return;  // the grid is sized for pos_shift = 31
     }
     // Which two query tiles this workgroup owns.  Balanced pairing (J, NT-1-J) gives every
@@ -294,10 +306,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const int nkv = (Skv + kKV - 1) / kKV;
     // r0 = first row of a block, counted from pos_base - kv_off (= row 0 unless PAGED)
     auto tiles_for = [&](int r0) {
-        if (r0 - pos_shift >= Sq) return 0;
+        if ((r0 >> gsh) - pos_shift >= Sq) return 0;
         int n = nkv;
         if (CAUSAL) {
-            const int last = r0 + 31 + pos_base;  // last position of the block
+            const int last = ((r0 + 31) >> gsh) + pos_base;  // last position of the block
             if (last < 0) return 0;
             const int d = last / kKV + 1;
             n = d < n ? d : n;
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // key tiles the workgroup walks (same in every wave)
     int nsteps = nkv;
     if (CAUSAL) {
-        int last = tile_long * kQTile + kQTile - 1 + pos_base;
+        int last = ((tile_long * kQTile + kQTile - 1) >> gsh) + pos_base;
         last = last < Sq - 1 + kv_off ? last : Sq - 1 + kv_off;
         const int d = last < 0 ? 0 : last / kKV + 1;
         nsteps = d < nsteps ? d : nsteps;
@@ -332,12 +344,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         nsteps = k1 - tile0;
     }
     // a block with rows to store may have no keys at all (PAGED, context shorter than the chunk)
-    const bool liveA = rowA0 - pos_shift < Sq;
-    const bool liveB = tile_short != tile_long && rowB0 - pos_shift < Sq;
+    const bool liveA = (rowA0 >> gsh) - pos_shift < Sq;
+    const bool liveB = tile_short != tile_long && (rowB0 >> gsh) - pos_shift < Sq;
 
     Block A, B;  // qrow = the lane's query POSITION (= row unless PAGED)
-    A.qrow = rowA0 + pos_base + c;
-    B.qrow = rowB0 + pos_base + c;
+    A.qrow = ((rowA0 + c) >> gsh) + pos_base;
+    B.qrow = ((rowB0 + c) >> gsh) + pos_base;
+    A.r0 = rowA0;
+    B.r0 = rowB0;
     // reserves a[0:223] in the kernel descriptor; every later statement names them literally
     asm volatile("" ::: K1_AGPRS);
     constexpr ic<0> kA{};
@@ -929,11 +943,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             // this part's share of the rows: normalised O in bf16, then (m in the exp2 domain, l);
             // a block without keys in the part carries l = 0 and drops out of the merge
             if (live) {
-                const int vr = blk.qrow - pos_base;  // row inside the sequence's tiling
+                const int vr = blk.r0 + c;  // (packed) row inside the sequence's tiling
                 const int tile = vr / kQTile;
                 const int ur = ((tile == tile_long && tile_long != tile_short) ? kQTile : 0) + (vr & (kQTile - 1));
-                const size_t pairs_max = gridDim.x / (unsigned)Hq;
-                unsigned char *slot = split_ws + ((((size_t)b * Hq + hq) * pairs_max + J) * gridDim.z + blockIdx.z) *
+                const int Hu = Hkv * Gq;
+                const size_t pairs_max = gridDim.x / (unsigned)Hu;
+                unsigned char *slot = split_ws + ((((size_t)b * Hu + hu) * pairs_max + J) * gridDim.z + blockIdx.z) *
                                                      (size_t)kSplitSlotBytes;
                 __bf16 *op = reinterpret_cast<__bf16 *>(slot) + ur * kD + 4 * h;
 #pragma unroll
@@ -968,14 +983,15 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                     w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
                     *reinterpret_cast<u32x2 *>(stg + c * kORow + (32 * dt + 8 * i + 4 * h) * 2) = w;
                 }
-            const int row0 = blk.qrow - c - kv_off;  // the block's first query row
+            const int head0 = kvh * G + hg * gp;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int ri = 4 * r + (lane >> 4);
+                const int ri = 4 * r + (lane >> 4);  // row of the block: position and head of the group
                 const u32x4 x = *reinterpret_cast<const u32x4 *>(stg + ri * kORow + (lane & 15) * 16);
-                const int orow = row0 + ri;
+                const int orow = ((blk.r0 + ri) >> gsh) + pos_base - kv_off;
+                const int ohead = head0 + (ri & (gp - 1));
                 if (live && orow >= 0 && orow < Sq)
-                    *reinterpret_cast<u32x4 *>(o + (((int64_t)b * Sq + orow) * Hq + hq) * kD + (lane & 15) * 8) = x;
+                    *reinterpret_cast<u32x4 *>(o + (((int64_t)b * Sq + orow) * Hq + ohead) * kD + (lane & 15) * 8) = x;
             }
         }
         if (!KSPLIT && live && row >= 0 && row < Sq) {
@@ -996,21 +1012,24 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #endif
 }
 
-// Combines the P partials of every row (KSPLIT): grid = (16, pairs_max * Hq, num_seqs), 16 rows of
-// a unit per workgroup, 16 lanes x 16 bytes per row.  Tile geometry as in the kernel above.
+// Combines the P partials of every row (KSPLIT): grid = (16, pairs_max * Hu, num_seqs) with
+// Hu = Hq >> pack_shift units (kv head, head group); 16 rows of a unit per workgroup, 16 lanes x
+// 16 bytes per row.  Tile geometry and row packing as in the kernel above.
 __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
     const unsigned char *__restrict__ ws, __bf16 *__restrict__ o,
-    const int32_t *__restrict__ context_lens, int Sq, int Hq, int max_blocks_per_seq,
-    int pair_adjacent, int parts) {
+    const int32_t *__restrict__ context_lens, int Sq, int Hq, int Hkv, int max_blocks_per_seq,
+    int pair_adjacent, int parts, int pack_shift) {
     const int b = blockIdx.z;
-    const int hq = blockIdx.y % Hq, J = blockIdx.y / Hq;
-    const int pairs_max = gridDim.y / Hq;
+    const int gsh = pack_shift, gp = 1 << gsh;
+    const int Hu = Hq >> gsh;
+    const int hu = blockIdx.y % Hu, J = blockIdx.y / Hu;
+    const int pairs_max = gridDim.y / Hu;
     int Skv = context_lens[b];
     const int cap = max_blocks_per_seq * 16;
     Skv = Skv < 0 ? 0 : (Skv > cap ? cap : Skv);
     const int kv_off = Skv - Sq;
     const int pos_shift = kv_off & 31;
-    const int num_q_tiles = (Sq + pos_shift + kQTile - 1) / kQTile;
+    const int num_q_tiles = (((Sq + pos_shift) << gsh) + kQTile - 1) / kQTile;
     const int pairs = (num_q_tiles + 1) / 2;
     if (J >= pairs) return;
     int tile_long = num_q_tiles - 1 - J, tile_short = J;
@@ -1022,9 +1041,11 @@ __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
     const int ur = (blockIdx.x << 4) + (threadIdx.x >> 4);
     const int ch = threadIdx.x & 15;
     if (ur >= kQTile && tile_long == tile_short) return;
-    const int row = (ur >= kQTile ? tile_long : tile_short) * kQTile + (ur & (kQTile - 1)) - pos_shift;
+    const int rho = (ur >= kQTile ? tile_long : tile_short) * kQTile + (ur & (kQTile - 1));  // packed row
+    const int row = (rho >> gsh) - pos_shift;
     if (row < 0 || row >= Sq) return;
-    const unsigned char *slot0 = ws + (((size_t)b * Hq + hq) * pairs_max + J) * parts * (size_t)kSplitSlotBytes;
+    const int hq = (hu % Hkv) * (Hq / Hkv) + (hu / Hkv) * gp + (rho & (gp - 1));
+    const unsigned char *slot0 = ws + (((size_t)b * Hu + hu) * pairs_max + J) * parts * (size_t)kSplitSlotBytes;
     float mmax = -INFINITY;
     for (int p = 0; p < parts; ++p) {
         const float *ml = reinterpret_cast<const float *>(slot0 + (size_t)p * kSplitSlotBytes + 2 * kQTile * kD * 2) + 2 * ur;
@@ -1093,11 +1114,11 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     if (a.causal)
         flash_attn_mfma_kernel<true, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0);
     else
         flash_attn_mfma_kernel<false, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0);
     return hipGetLastError();
 }
 
@@ -1119,14 +1140,39 @@ bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a) {
 }
 
 namespace {
+// Head packing of a paged launch (see the kernel): the group's heads go into the rows when the
+// group size is 2, 4 or 8.  Short chunks gain most (T = 32 at 32Q/8KV, 256 sequences: 1420 -> 500
+// us); long ones gain a little from the shorter diagonal (NVLLM_K1_PACK=0 switches it off).
+int paged_pack_shift(const PagedAttnArgs &a) {
+    const int G = a.num_heads / a.num_kv_heads;
+    int gsh = G == 2 ? 1 : (G == 4 ? 2 : (G == 8 ? 3 : 0));
+    if (const char *e = getenv("NVLLM_K1_PACK")) {
+        const int v = atoi(e);
+        if (v == 0) return 0;
+        if (v > 0) return gsh;
+    }
+    return gsh;
+}
+struct PagedGeom {
+    int gsh, units, num_q_tiles, pairs;
+};
+PagedGeom paged_geom(const PagedAttnArgs &a) {
+    PagedGeom g;
+    g.gsh = paged_pack_shift(a);
+    g.units = a.num_heads >> g.gsh;
+    // query positions are tiled from a multiple of 32: up to 31 dead positions in front of a sequence
+    g.num_q_tiles = (((a.num_new_tokens + 31) << g.gsh) + kQTile - 1) / kQTile;
+    g.pairs = (g.num_q_tiles + 1) / 2;
+    return g;
+}
 // Key-split factor of a paged launch: enough parts to put about one workgroup on every CU, at
 // least 8 key tiles (512 keys) per part by the longest context the tables allow, at most 8.
-int paged_ksplit_parts(const PagedAttnArgs &a, int pairs) {
+int paged_ksplit_parts(const PagedAttnArgs &a, const PagedGeom &g) {
     if (const char *e = getenv("NVLLM_K1_KSPLIT")) {
         const int v = atoi(e);
         if (v >= 1) return v > 16 ? 16 : v;
     }
-    const long long units = (long long)pairs * a.num_heads * a.num_seqs;
+    const long long units = (long long)g.pairs * g.units * a.num_seqs;
     const long long cus = device_cus();
     if (units * 2 > cus) return 1;
     long long parts = cus / units;
@@ -1138,18 +1184,15 @@ int paged_ksplit_parts(const PagedAttnArgs &a, int pairs) {
 }  // namespace
 
 size_t flash_attn_paged_workspace_bytes(const PagedAttnArgs &a) {
-    const int num_q_tiles = (a.num_new_tokens + 31 + kQTile - 1) / kQTile;
-    const int pairs = (num_q_tiles + 1) / 2;
-    const int parts = paged_ksplit_parts(a, pairs);
+    const PagedGeom g = paged_geom(a);
+    const int parts = paged_ksplit_parts(a, g);
     if (parts <= 1) return 0;
-    return (size_t)a.num_seqs * a.num_heads * pairs * parts * kSplitSlotBytes;
+    return (size_t)a.num_seqs * g.units * g.pairs * parts * kSplitSlotBytes;
 }
 
 hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
-    // query positions are tiled from a multiple of 32: up to 31 dead rows in front of a sequence
-    const int num_q_tiles = (a.num_new_tokens + 31 + kQTile - 1) / kQTile;
-    const int pairs = (num_q_tiles + 1) / 2;
-    int pair_adjacent = (int64_t)pairs * a.num_heads * a.num_seqs >= (int64_t)2 * device_cus();
+    const PagedGeom g = paged_geom(a);
+    int pair_adjacent = (int64_t)g.pairs * g.units * a.num_seqs >= (int64_t)2 * device_cus();
     if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
     const dim3 block(64 * kWaves);
     const float scale_log2e = a.scale * 1.4426950408889634f;
@@ -1158,26 +1201,29 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     auto kc = static_cast<const __bf16 *>(a.k_cache);
     auto vc = static_cast<const __bf16 *>(a.v_cache);
     auto o = static_cast<__bf16 *>(a.out);
-    const int parts = paged_ksplit_parts(a, pairs);
-    const size_t need = (size_t)a.num_seqs * a.num_heads * pairs * parts * kSplitSlotBytes;
+    const int parts = paged_ksplit_parts(a, g);
+    const size_t need = (size_t)a.num_seqs * g.units * g.pairs * parts * kSplitSlotBytes;
     if (parts > 1 && a.workspace && a.workspace_bytes >= need &&
         (reinterpret_cast<uintptr_t>(a.workspace) & 15u) == 0) {
         auto ws = static_cast<unsigned char *>(a.workspace);
-        const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs, (unsigned)parts);
+        const dim3 grid((unsigned)(g.pairs * g.units), (unsigned)a.num_seqs, (unsigned)parts);
         flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(
-            q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, ws);
+            q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
+            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, ws,
+            g.gsh);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
-        const dim3 mgrid(16, (unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs);
+        const dim3 mgrid(16, (unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
         flash_attn_ksplit_merge_kernel<<<mgrid, dim3(256), 0, stream>>>(
-            ws, o, a.context_lens, a.num_new_tokens, a.num_heads, a.max_blocks_per_seq, pair_adjacent, parts);
+            ws, o, a.context_lens, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.max_blocks_per_seq,
+            pair_adjacent, parts, g.gsh);
         return hipGetLastError();
     }
-    const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.num_seqs);
+    const dim3 grid((unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
     flash_attn_mfma_kernel<true, true, false><<<grid, block, 0, stream>>>(
-        q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, num_q_tiles,
-        pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, nullptr);
+        q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
+        pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, nullptr,
+        g.gsh);
     return hipGetLastError();
 }
 

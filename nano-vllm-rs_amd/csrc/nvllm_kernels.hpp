@@ -64,7 +64,7 @@ struct PagedAttnArgs {
     float scale;
 };
 // true when the bandwidth (MFMA) kernel covers this shape
-bool paged_attn_fast_path(DType dt, int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
+bool paged_attn_fast_path(DType dt, int num_new_tokens, int num_heads, int num_kv_heads,
                           int head_dim, int block_size);
 // split-K factor chosen for a launch shape (also sizes the workspace)
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq);

@@ -84,7 +84,6 @@ constexpr int kBS = 16;          // block_size of the fast path
 constexpr int kRowBytes = kD * 2;
 constexpr int kTileBlocks = 2;   // 32 tokens per tile
 constexpr int kLdsPerWave = kTileBlocks * kBS * kRowBytes;  // 8 KiB
-constexpr int kMaxChunks = 4;     // token chunks per sequence the decode kernel takes (see launch_paged_attn)
 constexpr int kMaxFastRows = 48;  // query rows (T * Hq/Hkv) per kv head the decode kernel takes
                                   // (a fourth query tile no longer fits 512 registers)
 
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     const int32_t *__restrict__ context_lens, __bf16 *__restrict__ out,
     float *__restrict__ ws_o, float *__restrict__ ws_ml, int T, int Hq, int Hkv,
     int max_blocks_per_seq, int64_t num_cache_blocks, float scale_log2e, int num_splits,
-    int blocks_per_split, int num_chunks, int chunk_tokens) {
+    int blocks_per_split) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[HPB * kLdsPerWave];
 
     const int lane = threadIdx.x & 63;
@@ -121,26 +120,13 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     const int g = lane >> 4;   // lane group
     const int c = lane & 15;   // query row within a q tile / token row / d within a d tile
     const int split = blockIdx.x;
-    // blockIdx.y = (sequence, token chunk): more new tokens than the query tiles hold are cut into
-    // chunks of chunk_tokens; chunk j is the same problem with Tc tokens and the context that ends
-    // at its last token, so the bottom-right mask needs nothing else.
-    // Eight sequences form a group of 8 * num_chunks grid rows, chunk-major inside it: the chunks
-    // of one sequence are 8 rows apart, i.e. on the same XCD (workgroups go round the 8 XCDs in
-    // dispatch order) and dispatched together, so whichever runs ahead fills that XCD's L2 for the
-    // others.
-    const int num_seqs = (int)gridDim.y / num_chunks;
-    const int grp = (int)blockIdx.y / (8 * num_chunks);
-    const int in_grp = (int)blockIdx.y - grp * 8 * num_chunks;
-    const int grp_seqs = num_seqs - 8 * grp < 8 ? num_seqs - 8 * grp : 8;
-    const int seq = 8 * grp + in_grp % grp_seqs;
-    const int tok_first = (in_grp / grp_seqs) * chunk_tokens;  // first new token of this chunk
-    const int Tc = T - tok_first < chunk_tokens ? T - tok_first : chunk_tokens;
+    const int seq = blockIdx.y;
     const int kvh = blockIdx.z * HPB + wave;
     if (kvh >= Hkv) return;  // whole wave; no barriers are used anywhere
 
     const int G = Hq / Hkv;
-    const int R = Tc * G;
-    const int ctx = context_lens[seq] - (T - tok_first - Tc);
+    const int R = T * G;
+    const int ctx = context_lens[seq];
     int nblk_seq = ctx > 0 ? (ctx + kBS - 1) / kBS : 0;
     if (nblk_seq > max_blocks_per_seq) nblk_seq = max_blocks_per_seq;  // never read past the table row
     const int blk_begin = split * blocks_per_split;
@@ -159,7 +145,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
         const bool valid = r < R;
         const int t = valid ? r / G : 0;
         const int hg = valid ? r - t * G : 0;
-        const __bf16 *qrow = q + (((int64_t)seq * T + tok_first + t) * Hq + kvh * G + hg) * kD;
+        const __bf16 *qrow = q + (((int64_t)seq * T + t) * Hq + kvh * G + hg) * kD;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 x = u32x4{0u, 0u, 0u, 0u};
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
 
     // first token that some query row cannot see (bottom-right mask); tiles
     // that end at or before it need no masking at all
-    const int first_masked_tok = ctx - (Tc - 1);
+    const int first_masked_tok = ctx - (T - 1);
 
     auto compute_tile = [&](TileRegs &tr, int t) {
         const int tok0 = (blk_begin + kTileBlocks * t) * kBS;
@@ -295,7 +281,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sv[4 * b + j] = s[qt][b][j] * scale_log2e;
             if (tail) {
-                const int limit = ctx - Tc + t_of_row[qt];  // last visible key position
+                const int limit = ctx - T + t_of_row[qt];  // last visible key position
 #pragma unroll
                 for (int b = 0; b < kTileBlocks; ++b)
 #pragma unroll
@@ -352,7 +338,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     // bytes.  Each lane compares one tile's first block id; one ballot finds the prefix length.
     int nshared = NT ? 0 : ntiles;
     if (NT && ntiles > 0) {
-        const int nb_seq = (seq ^ 1) < num_seqs ? (seq ^ 1) : seq;
+        const int nb_seq = (seq ^ 1) < (int)gridDim.y ? (seq ^ 1) : seq;
         if (nb_seq != seq) {
             const int32_t *table_nb = block_tables + (int64_t)nb_seq * max_blocks_per_seq;
             nshared = ntiles;
@@ -404,7 +390,7 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
         const int r = qt * 16 + c;
         if (r >= R) continue;
         const int t = r / G, hg = r - t * G;
-        const int64_t orow = ((int64_t)seq * T + tok_first + t) * Hq + kvh * G + hg;
+        const int64_t orow = ((int64_t)seq * T + t) * Hq + kvh * G + hg;
         if (num_splits == 1) {
             const float inv = l > 0.0f ? 1.0f / l : 0.0f;
             __bf16 *op = out + orow * kD + 4 * g;
@@ -561,8 +547,8 @@ int env_int(const char *name, int dflt) {
 
 template <int NQT, int HPB>
 void launch_fast(const PagedAttnArgs &a, int splits, int bps, float *ws_o, float *ws_ml,
-                 bool nt, int num_chunks, int chunk_tokens, hipStream_t stream) {
-    const dim3 grid(splits, a.num_seqs * num_chunks, (a.num_kv_heads + HPB - 1) / HPB), block(64 * HPB);
+                 bool nt, hipStream_t stream) {
+    const dim3 grid(splits, a.num_seqs, (a.num_kv_heads + HPB - 1) / HPB), block(64 * HPB);
     const float scale_log2e = a.scale * 1.4426950408889634f;
     auto q = static_cast<const __bf16 *>(a.q);
     auto kc = static_cast<const unsigned char *>(a.k_cache);
@@ -572,33 +558,20 @@ void launch_fast(const PagedAttnArgs &a, int splits, int bps, float *ws_o, float
         paged_attn_kernel<NQT, HPB, true><<<grid, block, 0, stream>>>(
             q, kc, vc, a.block_tables, a.context_lens, o, ws_o, ws_ml, a.num_new_tokens,
             a.num_heads, a.num_kv_heads, a.max_blocks_per_seq, a.num_cache_blocks, scale_log2e,
-            splits, bps, num_chunks, chunk_tokens);
+            splits, bps);
     else
         paged_attn_kernel<NQT, HPB, false><<<grid, block, 0, stream>>>(
             q, kc, vc, a.block_tables, a.context_lens, o, ws_o, ws_ml, a.num_new_tokens,
             a.num_heads, a.num_kv_heads, a.max_blocks_per_seq, a.num_cache_blocks, scale_log2e,
-            splits, bps, num_chunks, chunk_tokens);
+            splits, bps);
 }
 
 }  // namespace
 
-bool paged_attn_fast_path(DType dt, int num_seqs, int T, int Hq, int Hkv, int D, int block_size) {
+bool paged_attn_fast_path(DType dt, int T, int Hq, int Hkv, int D, int block_size) {
     if (dt != DType::BF16 || D != kD || block_size != kBS) return false;
     if (Hkv <= 0 || Hq % Hkv != 0 || T <= 0) return false;
-    const int G = Hq / Hkv;
-    if (G > kMaxFastRows) return false;
-    // Up to kMaxFastRows query rows per kv head in one workgroup; more new tokens as token chunks,
-    // each of which walks the sequence's K/V again (partly from cache), as long as that measured
-    // faster than the prefill kernel's 128-position tiles at 32Q/8KV: 2 chunks from 2 sequences
-    // up, 3 from 32, 4 from 128 (scripts/diag/verify_T_sweep.py).
-    const int per_chunk = kMaxFastRows / G;
-    const int chunks = (T + per_chunk - 1) / per_chunk;
-    const int forced = env_int("NVLLM_PAGED_MAX_CHUNKS", 0);
-    if (forced > 0) return chunks <= forced;
-    if (chunks == 1) return true;
-    if (chunks == 2) return num_seqs >= 2;
-    if (chunks == 3) return num_seqs >= 32;
-    return chunks <= kMaxChunks && num_seqs >= 128;
+    return T * (Hq / Hkv) <= kMaxFastRows;
 }
 
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq) {
@@ -623,7 +596,7 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
 
 size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
                                   int max_blocks_per_seq) {
-    if (!paged_attn_fast_path(DType::BF16, num_seqs, T, Hq, Hkv, D, block_size)) {
+    if (!paged_attn_fast_path(DType::BF16, T, Hq, Hkv, D, block_size)) {
         // more query rows per kv head than the decode kernel takes: the prefill kernel over the
         // cache, which splits the key walk of a small launch and needs room for the partials
         if (D == kD && block_size == kBS && Hkv > 0 && Hq % Hkv == 0 && T > 0 && num_seqs > 0) {
@@ -645,7 +618,7 @@ size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, i
 
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {
     if (a.num_seqs <= 0) return hipSuccess;
-    if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
+    if (paged_attn_fast_path(dt, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                              a.block_size)) {
         int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);
         const size_t rows = (size_t)a.num_seqs * a.num_new_tokens * a.num_heads;
@@ -658,13 +631,8 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         // adaptive non-temporal K/V loads, unless the K/V the tables can reach fits the 256 MiB
         // Infinity Cache anyway (then a later layer / step may still find it there)
         const int64_t reach = (int64_t)a.num_seqs * a.max_blocks_per_seq * 2 * kBS * a.num_kv_heads * kRowBytes;
-        const int G = a.num_heads / a.num_kv_heads;
-        // new tokens beyond one workgroup's query tiles: equal token chunks, one workgroup each
-        const int num_chunks = (a.num_new_tokens + kMaxFastRows / G - 1) / (kMaxFastRows / G);
-        const int chunk_tokens = (a.num_new_tokens + num_chunks - 1) / num_chunks;
-        // chunks of a sequence re-read its K/V: leave it in the caches for them
-        const bool nt = env_int("NVLLM_PAGED_NT", (reach > ((int64_t)256 << 20) && num_chunks == 1) ? 1 : 0) != 0;
-        const int R = chunk_tokens * G;
+        const bool nt = env_int("NVLLM_PAGED_NT", reach > ((int64_t)256 << 20) ? 1 : 0) != 0;
+        const int R = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
         // kv heads per workgroup: 8 waves sharing a block's rows is the throughput shape; a launch
         // of fewer workgroups than CUs spreads its heads over more of them instead
         int hpb = env_int("NVLLM_PAGED_HPB", 0);
@@ -678,14 +646,14 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
                     n = 256;
                 num_cus = n;
             }
-            while (hpb > 1 && (long)splits * a.num_seqs * num_chunks * ((a.num_kv_heads + hpb - 1) / hpb) < num_cus) hpb /= 2;
+            while (hpb > 1 && (long)splits * a.num_seqs * ((a.num_kv_heads + hpb - 1) / hpb) < num_cus) hpb /= 2;
         }
         // two or more query tiles need the 512-register budget of a 4-wave workgroup (with 8 waves
         // the kernel spilled and ran at half the bandwidth)
         if (R > 16 && hpb > 4) hpb = 4;
         const int nqt = (R + 15) / 16;
 #define NVLLM_PAGED_CASE(NQT, HPB) \
-    case NQT * 16 + HPB: launch_fast<NQT, HPB>(a, splits, bps, ws_o, ws_ml, nt, num_chunks, chunk_tokens, stream); break;
+    case NQT * 16 + HPB: launch_fast<NQT, HPB>(a, splits, bps, ws_o, ws_ml, nt, stream); break;
         switch (nqt * 16 + hpb) {
             NVLLM_PAGED_CASE(1, 8) NVLLM_PAGED_CASE(1, 4) NVLLM_PAGED_CASE(1, 2) NVLLM_PAGED_CASE(1, 1)
             NVLLM_PAGED_CASE(2, 4) NVLLM_PAGED_CASE(2, 2) NVLLM_PAGED_CASE(2, 1)

@@ -140,19 +140,15 @@ def test_fast_path_32_query_rows(dev):
     assert_attention_close(got, want)
 
 
-@pytest.mark.parametrize("T,splits", [(9, 0), (12, 0), (13, 0), (16, 0), (17, 2), (24, 0), (24, 3), (30, 0), (47, 0), (48, 2)])
-def test_token_chunks_in_the_decode_kernel(dev, T, splits, monkeypatch):
-    """More than 32 query rows per kv head: a third query tile (T = 9..12 at G = 4), then token
-    chunks of equal size, one workgroup each (13..48; uneven last chunk at 13, 17, 47), with and
-    without split-K.  NVLLM_PAGED_MAX_CHUNKS pins the decode kernel for every case, whatever the
-    batch-size rule of the launcher would pick."""
-    monkeypatch.setenv("NVLLM_PAGED_MAX_CHUNKS", "4")
+@pytest.mark.parametrize("T,splits", [(9, 0), (10, 2), (12, 0), (12, 3), (13, 0), (16, 0), (24, 0), (30, 0), (47, 0)])
+def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, monkeypatch):
+    """More than 32 query rows per kv head: the decode kernel's third query tile (T = 9..12 at
+    G = 4; with and without split-K), then the prefill kernel over the cache with the head group
+    packed into its rows (T >= 13)."""
     if splits:
         monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
     Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(900 + T)
-    # contexts: exactly T, ragged, multi-block; 11 sequences so that the last group of 8 grid rows
-    # is a ragged one
     ctx_lens = [max(T, c) for c in (T, T + 3, T + 1, 16, 47, 48, 49, 130, 300, 515, 1000)]
     kc, vc, tables = make_paged_case(rng, ctx_lens, 300, bs, Hkv, D, slack_blocks=1)
     q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
@@ -162,39 +158,23 @@ def test_token_chunks_in_the_decode_kernel(dev, T, splits, monkeypatch):
     assert_attention_close(got, want)
 
 
-def test_token_chunks_agree_with_the_prefill_kernel(dev, monkeypatch):
-    """The same launch through both kernels (decode kernel in 3 chunks / prefill kernel over the
-    cache): both within the bar of the oracle and of each other."""
-    Hq, Hkv, D, bs, T = 32, 8, 128, 16, 30
-    rng = np.random.default_rng(930)
-    ctx_lens = [30, 64, 100, 257, 640]
-    kc, vc, tables = make_paged_case(rng, ctx_lens, 200, bs, Hkv, D, slack_blocks=1)
-    q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
-    scale = 1.0 / math.sqrt(D)
-    monkeypatch.setenv("NVLLM_PAGED_MAX_CHUNKS", "4")
-    a = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale)
-    monkeypatch.setenv("NVLLM_PAGED_MAX_CHUNKS", "1")
-    b = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale)
-    want = oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, scale)
-    assert_attention_close(a, want)
-    assert_attention_close(b, want)
-    assert_attention_close(a, b)
-
-
-def test_token_chunks_context_shorter_than_the_new_tokens(dev, monkeypatch):
-    """Invalid for the reference (ctx >= T there); like the other kernels, rows whose position is
-    negative come out zero -- here whole chunks can fall in front of the context."""
-    Hq, Hkv, D, bs, T = 32, 8, 128, 16, 30
+@pytest.mark.parametrize("T", [12, 30])
+def test_context_shorter_than_the_new_tokens(dev, monkeypatch, T):
+    """Invalid for the reference (ctx >= T there); every kernel gives rows whose position is
+    negative a zero output (T = 12: decode kernel, T = 30: packed prefill kernel; against the
+    generic kernel)."""
+    Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(931)
-    ctx_lens = [0, 7, 19, 29]
+    ctx_lens = [0, 7, 11, T - 1]
     kc, vc, tables = make_paged_case(rng, [64] * 4, 40, bs, Hkv, D)
     q = bf16_randn(rng, (4, T, Hq, D))
     scale = 1.0 / math.sqrt(D)
-    monkeypatch.setenv("NVLLM_PAGED_MAX_CHUNKS", "4")
     got = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale)
-    monkeypatch.setenv("NVLLM_PAGED_MAX_CHUNKS", "1")
-    monkeypatch.setenv("NVLLM_PAGED_FLASH", "0")          # the generic kernel
-    want = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    gen = nv.paged_attention_batched(f32(q).to(dev), f32(kc).to(dev), f32(vc).to(dev),
+                                     torch.from_numpy(pad_tables(tables, None)).to(dev),
+                                     torch.tensor(ctx_lens, dtype=torch.int32, device=dev), scale)
+    want = gen.float().cpu().numpy()      # f32 tensors run the generic kernel
     for i, ctx in enumerate(ctx_lens):
         assert (got[i, :T - ctx] == 0).all()
     assert_attention_close(got, want)

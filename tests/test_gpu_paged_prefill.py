@@ -1,4 +1,4 @@
-"""K1 over the paged cache: chunked prefill / long verify (launches the decode kernel does not take: more than 48 query rows per kv head, or more than a few such chunks).
+"""K1 over the paged cache: chunked prefill / long verify (more than 48 query rows per kv head).
 
 Same contract and oracle as the decode tests (oracle.paged_attention restates reference
 src/attention/paged.rs:117-192; the bottom-right causal mask is paged.rs:357-381): T new tokens
@@ -122,13 +122,18 @@ def test_large_scores_stay_finite(dev):
     assert_attention_close(got, want, max_tol=5e-2, mean_tol=5e-3)
 
 
+@pytest.mark.parametrize("pack", [None, "0"])
 @pytest.mark.parametrize("S,T", [(4096, 4096), (4096, 512), (3000, 1000), (8192, 2048)])
-def test_paged_chunk_equals_contiguous_prefill(dev, S, T):
+def test_paged_chunk_equals_contiguous_prefill(dev, monkeypatch, S, T, pack):
     """Size-independent property at sizes the oracle would take minutes on: K/V written through
     reshape_and_cache and read back through the block table give the last T rows of the
     contiguous causal prefill over the same K/V (the K1 dense path, itself pinned to the oracle
-    in test_gpu_flash_attention.py).  With T == S the two walks are the same arithmetic in the
-    same order: the outputs must be bit-identical."""
+    in test_gpu_flash_attention.py).  With T == S and the head group NOT packed into the rows
+    (NVLLM_K1_PACK=0) the two walks are the same arithmetic in the same order: the outputs must be
+    bit-identical.  Packed (the default) a wave holds other rows, so its deferred-rescale decisions
+    may differ: same bar as everywhere else."""
+    if pack is not None:
+        monkeypatch.setenv("NVLLM_K1_PACK", pack)
     Hq, Hkv, D, bs = 32, 8, 128, 16
     g = torch.Generator(device="cpu").manual_seed(S + T)
     k = torch.randn((1, S, Hkv, D), generator=g).to(dev, torch.bfloat16)
@@ -149,7 +154,7 @@ def test_paged_chunk_equals_contiguous_prefill(dev, S, T):
     paged = nv.paged_attention(q[:, S - T:].contiguous(), layer, bt, S, Hq, Hkv, D, scale)
     torch.cuda.synchronize()
     want = dense[:, S - T:].reshape(1, T, Hq * D)
-    if T == S:
+    if T == S and pack == "0":
         assert torch.equal(paged, want)
     assert_attention_close(paged.float().cpu().numpy(), want.float().cpu().numpy())
 
