@@ -48,8 +48,10 @@ def test_chunk_lengths_and_alignments(dev, T):
 
 
 @pytest.mark.parametrize("heads", [dict(Hq=16, Hkv=8), dict(Hq=8, Hkv=8), dict(Hq=4, Hkv=1),
-                                   dict(Hq=64, Hkv=1)])
+                                   dict(Hq=64, Hkv=1), dict(Hq=16, Hkv=2), dict(Hq=6, Hkv=2),
+                                   dict(Hq=16, Hkv=1)])
 def test_head_shapes(dev, heads):
+    # group sizes 2, 4, 8 are packed into the rows; 1, 3, 16, 64 are not
     Hq, Hkv, D, bs = heads["Hq"], heads["Hkv"], 128, 16
     T = 1 if Hq // Hkv > 32 else 70           # Hq/Hkv = 64: even T = 1 exceeds the decode kernel
     rng = np.random.default_rng(Hq * 10 + Hkv)
