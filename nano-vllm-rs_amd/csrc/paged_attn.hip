@@ -415,16 +415,21 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     }
 }
 
-// K2b: combine split-K partials.  One wave per output row (seq, t, head).  The (m, l) pairs of
-// the row's splits (at most 64, paged_attn_num_splits) are read one per lane and reduced across
-// the wave; then lane owns d = 2*lane, 2*lane+1 and walks the splits with independent loads.
+// K2b: combine split-K partials.  One 4-wave workgroup per output row (seq, t, head): small
+// launches are pure latency, so the row's splits are spread over the whole workgroup instead of
+// walked one after the other.  Every wave reads the (m, l) pairs of all splits (at most 64,
+// paged_attn_num_splits), one per lane, and reduces them to the row's max and denominator; then
+// half-wave (w, hf) takes the splits s = 8i + 2w + hf, its lane dl owning d = 4 dl .. 4 dl + 3
+// (16-byte loads, all independent), and the eight partial sums meet in LDS.
 __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float *__restrict__ ws_o,
                                                                const float *__restrict__ ws_ml,
                                                                __bf16 *__restrict__ out,
                                                                int64_t num_rows, int num_splits) {
+    __shared__ __attribute__((aligned(16))) float part[8][kD];
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= num_rows) return;
+    const int wave = threadIdx.x >> 6;
+    const int hf = lane >> 5, dl = lane & 31;
+    const int64_t row = blockIdx.x;
     float ms = -INFINITY, ls = 0.0f;
     if (lane < num_splits) {
         const float2 x = *reinterpret_cast<const float2 *>(ws_ml + 2 * (row * num_splits + lane));
@@ -438,16 +443,29 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float *__re
     float L = ls * w_lane;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) L += __shfl_xor(L, off);
-    float o0 = 0.0f, o1 = 0.0f;
-#pragma unroll 8
-    for (int s = 0; s < num_splits; ++s) {
-        const float w = __shfl(w_lane, s);
-        const float2 o = *reinterpret_cast<const float2 *>(ws_o + (row * num_splits + s) * kD + 2 * lane);
-        o0 += o.x * w;
-        o1 += o.y * w;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = 2 * wave + hf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // 64 splits at most
+        const int sp = 8 * i + s0;
+        const float w = __shfl(w_lane, sp & 63);
+        if (sp < num_splits) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(ws_o + (row * num_splits + sp) * kD + 4 * dl);
+            acc += o * w;
+        }
     }
-    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
-    *reinterpret_cast<unsigned *>(out + row * kD + 2 * lane) = pack_bf16x2(o0 * inv, o1 * inv);
+    *reinterpret_cast<f32x4 *>(&part[2 * wave + hf][4 * dl]) = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        f32x4 t = *reinterpret_cast<const f32x4 *>(&part[0][4 * dl]);
+#pragma unroll
+        for (int p = 1; p < 8; ++p) t += *reinterpret_cast<const f32x4 *>(&part[p][4 * dl]);
+        const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+        uint2 y;
+        y.x = pack_bf16x2(t[0] * inv, t[1] * inv);
+        y.y = pack_bf16x2(t[2] * inv, t[3] * inv);
+        *reinterpret_cast<uint2 *>(out + row * kD + 4 * dl) = y;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -664,7 +682,7 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         if (splits > 1) {
-            const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+            const dim3 grid((unsigned)rows), block(256);
             paged_attn_merge_kernel<<<grid, block, 0, stream>>>(
                 ws_o, ws_ml, static_cast<__bf16 *>(a.out), (int64_t)rows, splits);
             err = hipGetLastError();
