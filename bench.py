@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the attention hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|prefill|kvwrite|producer]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|verify|prefill|kvwrite|producer]
 
 Headline (default, BASELINE.json `metric`): paged-decode attention GB/s on
 BASELINE config 3 -- 256 sequences x 2048-token contexts, 32 Q / 8 KV heads,
@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="decode",
-                    choices=["decode", "shared", "long", "prefill", "kvwrite", "producer"])
+                    choices=["decode", "shared", "long", "verify", "prefill", "kvwrite", "producer"])
+    ap.add_argument("--tokens", type=int, default=8, help="new tokens per sequence (--workload verify)")
     ap.add_argument("--num-seqs", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=0)
     ap.add_argument("--layers", type=int, default=0, help="disjoint layer caches rotated over")
@@ -198,6 +199,11 @@ def run_decode(args, nv, dev, rank, world, workload):
         pool = None
         name = ("config4: shared-prefix decode + spec-verify, %d seqs, T=4, ctx %d = %d shared + %d private"
                 % (num_seqs, ctx, shared, ctx - shared))
+    elif workload == "verify":    # config 3's batch with T new tokens per sequence
+        num_seqs, ctx, T, shared = args.num_seqs or 256, args.ctx or 2048, args.tokens, 0
+        layers = args.layers or 2
+        pool = None
+        name = "verify: %d seqs x %d ctx, T=%d new tokens, 32Q/8KV, hd128, block 16" % (num_seqs, ctx, T)
     else:                          # BASELINE config 5 (per-GPU shard of 1024/n sequences)
         total = args.num_seqs or 1024
         num_seqs, ctx, T, shared = max(total // max(args.gpus, 1), 1), args.ctx or 32768, 1, 0
@@ -381,7 +387,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     import nano_vllm_rs_amd as nv
     nv.capi.lib()
-    if args.workload in ("decode", "shared", "long"):
+    if args.workload in ("decode", "shared", "long", "verify"):
         res = run_decode(args, nv, dev, rank, world, args.workload)
         if args.workload == "decode" and not args.num_seqs and not args.ctx:
             res["roofline"]["traffic"] = pmc_traffic("config3_decode")
@@ -399,6 +405,16 @@ def main():
                            if k in p}
         if "cpu_baseline" in p:
             also["prefill"]["cpu_baseline"] = p["cpu_baseline"]
+        saved = (args.steps, args.warmup, args.no_cpu_baseline, args.tokens)
+        args.steps, args.warmup, args.no_cpu_baseline = max(args.steps // 4, 5), max(args.warmup // 4, 2), True
+        for t in (8, 32):   # multi-token verify / short chunk on config 3's batch: decode kernel, prefill kernel
+            args.tokens = t
+            torch.cuda.empty_cache()
+            w = run_decode(args, nv, dev, rank, world, "verify")
+            also["verify_T%d" % t] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
+                                          frac=w["roofline"]["frac"])
+        args.steps, args.warmup, args.no_cpu_baseline, args.tokens = saved
+        torch.cuda.empty_cache()
         for n in (256, 4096, 32768):
             w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, n)
             also["kv_write_%d" % n] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
