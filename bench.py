@@ -243,7 +243,7 @@ def run_decode(args, nv, dev, rank, world, workload):
                       traffic=None, kernel="paged_attn_kernel",
                       launch_ms=ev_ms, effective_logical_GBps=logical_bytes / (ev_ms * 1e-3) / 1e9),
     )
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
         budget = args.cpu_seconds if workload != "long" else args.cpu_seconds
         cb, want = cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget,
                                        ctx * token_bytes)
@@ -282,7 +282,7 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
                       unit="TFLOP/s", frac=flops / (ev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                       traffic=None, kernel="flash_attn", launch_ms=ev_ms),
     )
-    if rank == 0 and cpu and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         import oracle
         # sample: every head of batch element 0 (the whole workload at B=1), repeated to ~budget
         hs = Hq
