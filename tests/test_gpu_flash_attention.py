@@ -223,3 +223,30 @@ def test_mfma_linearity_in_v(dev):
     # first query row attends to key 0 only: output equals V[0] exactly
     assert torch.equal(nv.flash_attention(q, k, v1, cfg)[:, 0, :, :].reshape(B, Hkv, 2, D)[:, :, 0],
                        v1[:, 0])
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_mfma_random_shapes_match_the_generic_kernel(dev, seed):
+    """Randomised (B, Sq, Skv, heads, causal) through the MFMA kernel against the generic kernel on
+    the same values in f32 (the generic kernel is pinned to the oracle above): every phase
+    combination of the tile walk (both blocks, one block, masked last tiles in either, ragged
+    rows and keys, balanced and adjacent tile pairs)."""
+    rng = np.random.default_rng(seed)
+    for case in range(30):
+        Hkv = int(rng.choice([1, 2, 4, 8]))
+        Hq = Hkv * int(rng.choice([1, 2, 4, 8]))
+        B = int(rng.integers(1, 4))
+        Sq = int(rng.choice([1, 31, 32, 33, 64, 127, 128, 129, 255, 256, 257, 300, 500, 777, 1030]))
+        causal = bool(rng.integers(0, 2))
+        Skv = Sq if rng.random() < 0.6 else int(rng.integers(1, 1100))
+        g = torch.Generator(device="cpu").manual_seed(1000 * seed + case)
+        q = torch.randn((B, Sq, Hq, 128), generator=g).to(dev, torch.bfloat16)
+        k = torch.randn((B, Skv, Hkv, 128), generator=g).to(dev, torch.bfloat16)
+        v = torch.randn((B, Skv, Hkv, 128), generator=g).to(dev, torch.bfloat16)
+        cfg = nv.FlashAttentionConfig.new(128, causal)
+        got = nv.flash_attention(q, k, v, cfg).float()
+        want = nv.flash_attention(q.float(), k.float(), v.float(), cfg)
+        err = (got - want).abs()
+        what = dict(case=case, B=B, Sq=Sq, Skv=Skv, Hq=Hq, Hkv=Hkv, causal=causal)
+        assert bool(torch.isfinite(got).all()), what
+        assert float(err.max()) < 2e-2 and float(err.mean()) < 1e-3, (what, float(err.max()), float(err.mean()))
