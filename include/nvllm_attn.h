@@ -93,7 +93,8 @@ int nvllm_flash_attn_fwd_f32(const void *q, const void *k, const void *v, void *
  * `workspace` is split-K scratch of at least nvllm_paged_attn_workspace_bytes()
  * bytes (may be NULL when that returns 0).
  * bf16, head_dim 128, block_size 16: num_new_tokens * (num_heads/num_kv_heads)
- * <= 48 runs the bandwidth kernel (decode, short verify); more query rows
+ * <= 16 always runs the bandwidth kernel (decode, short verify), up to 48 when
+ * the launch is large or the contexts long; more query rows
  * (chunked prefill, long verify) run the prefill kernel reading K/V through the
  * block table (needs a cache of < 64 GiB and < 2^24 blocks); other shapes run
  * the generic kernel. */

@@ -94,8 +94,8 @@ int paged_common(kernels::DType dt, const void *q, const void *k_cache, const vo
                              workspace ? workspace_bytes : 0, num_seqs, num_new_tokens, num_heads,
                              num_kv_heads, head_dim, block_size, max_blocks_per_seq,
                              num_cache_blocks, scale};
-    if (kernels::paged_attn_fast_path(dt, num_new_tokens, num_heads, num_kv_heads, head_dim,
-                                      block_size) &&
+    if (kernels::paged_attn_fast_path(dt, num_seqs, num_new_tokens, num_heads, num_kv_heads, head_dim,
+                                      block_size, max_blocks_per_seq) &&
         !(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(out)))
         return fail(ErrorKind::Config, "paged_attn: tensors must be 16-byte aligned");
     return hip_status(kernels::launch_paged_attn(dt, a, as_stream(stream)), "paged_attn launch");

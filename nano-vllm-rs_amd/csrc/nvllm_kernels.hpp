@@ -64,8 +64,8 @@ struct PagedAttnArgs {
     float scale;
 };
 // true when the bandwidth (MFMA) kernel covers this shape
-bool paged_attn_fast_path(DType dt, int num_new_tokens, int num_heads, int num_kv_heads,
-                          int head_dim, int block_size);
+bool paged_attn_fast_path(DType dt, int num_seqs, int num_new_tokens, int num_heads,
+                          int num_kv_heads, int head_dim, int block_size, int max_blocks_per_seq);
 // split-K factor chosen for a launch shape (also sizes the workspace)
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq);
 size_t paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,

@@ -84,6 +84,8 @@ constexpr int kBS = 16;          // block_size of the fast path
 constexpr int kRowBytes = kD * 2;
 constexpr int kTileBlocks = 2;   // 32 tokens per tile
 constexpr int kLdsPerWave = kTileBlocks * kBS * kRowBytes;  // 8 KiB
+constexpr int64_t kMultiTileMinTokens = 384 * 1024;  // see paged_attn_fast_path
+constexpr int64_t kMultiTileMinContext = 16384;
 constexpr int kMaxFastRows = 48;  // query rows (T * Hq/Hkv) per kv head the decode kernel takes
                                   // (a fourth query tile no longer fits 512 registers)
 
@@ -586,10 +588,22 @@ void launch_fast(const PagedAttnArgs &a, int splits, int bps, float *ws_o, float
 
 }  // namespace
 
-bool paged_attn_fast_path(DType dt, int T, int Hq, int Hkv, int D, int block_size) {
+bool paged_attn_fast_path(DType dt, int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
+                          int max_blocks_per_seq) {
     if (dt != DType::BF16 || D != kD || block_size != kBS) return false;
     if (Hkv <= 0 || Hq % Hkv != 0 || T <= 0) return false;
-    return T * (Hq / Hkv) <= kMaxFastRows;
+    const int R = T * (Hq / Hkv);
+    const int forced = env_int("NVLLM_PAGED_MAX_ROWS", 0);
+    if (forced > 0) return R <= (forced < kMaxFastRows ? forced : kMaxFastRows);
+    if (R <= 16) return true;
+    if (R > kMaxFastRows) return false;
+    // Two or three query tiles run 4 waves per workgroup; that pays where the launch is bound by
+    // HBM (measured at 32Q/8KV: 256 x 2048 and 128 x 8192 tokens of context and up) and on long
+    // contexts, where split-K spreads even one sequence over the chip (1 x 32768, T = 8: 40 us
+    // against 76 us).  Other launches are faster in the prefill kernel over the cache
+    // (32 x 4096, T = 12: 135 -> 112 us).
+    const int64_t max_ctx = (int64_t)max_blocks_per_seq * kBS;
+    return max_ctx >= kMultiTileMinContext || num_seqs * max_ctx >= kMultiTileMinTokens;
 }
 
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq) {
@@ -614,7 +628,7 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
 
 size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
                                   int max_blocks_per_seq) {
-    if (!paged_attn_fast_path(DType::BF16, T, Hq, Hkv, D, block_size)) {
+    if (!paged_attn_fast_path(DType::BF16, num_seqs, T, Hq, Hkv, D, block_size, max_blocks_per_seq)) {
         // more query rows per kv head than the decode kernel takes: the prefill kernel over the
         // cache, which splits the key walk of a small launch and needs room for the partials
         if (D == kD && block_size == kBS && Hkv > 0 && Hq % Hkv == 0 && T > 0 && num_seqs > 0) {
@@ -636,8 +650,8 @@ size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, i
 
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {
     if (a.num_seqs <= 0) return hipSuccess;
-    if (paged_attn_fast_path(dt, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
-                             a.block_size)) {
+    if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
+                             a.block_size, a.max_blocks_per_seq)) {
         int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);
         const size_t rows = (size_t)a.num_seqs * a.num_new_tokens * a.num_heads;
         if (splits > 1 && a.workspace_bytes < rows * splits * (kD + 2) * sizeof(float)) splits = 1;

@@ -127,8 +127,12 @@ def test_fast_path_multi_token_causal(dev, T):
     assert_attention_close(got, want)
 
 
-def test_fast_path_32_query_rows(dev):
-    # T=8 with G=4 -> two 16-row query tiles
+@pytest.mark.parametrize("pin", ["48", None])
+def test_fast_path_32_query_rows(dev, monkeypatch, pin):
+    # T=8 with G=4 -> two 16-row query tiles in the decode kernel (pinned: a launch this small
+    # would otherwise go to the prefill kernel over the cache, the second case)
+    if pin:
+        monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", pin)
     Hq, Hkv, D, bs, T = 32, 8, 128, 16, 8
     rng = np.random.default_rng(808)
     ctx_lens = [8, 40, 130, 515]
@@ -143,8 +147,10 @@ def test_fast_path_32_query_rows(dev):
 @pytest.mark.parametrize("T,splits", [(9, 0), (10, 2), (12, 0), (12, 3), (13, 0), (16, 0), (24, 0), (30, 0), (47, 0)])
 def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, monkeypatch):
     """More than 32 query rows per kv head: the decode kernel's third query tile (T = 9..12 at
-    G = 4; with and without split-K), then the prefill kernel over the cache with the head group
-    packed into its rows (T >= 13)."""
+    G = 4; with and without split-K; NVLLM_PAGED_MAX_ROWS pins the decode kernel, which the
+    launcher would only pick for an HBM-bound launch), then the prefill kernel over the cache with
+    the head group packed into its rows (T >= 13)."""
+    monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", "48")
     if splits:
         monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
     Hq, Hkv, D, bs = 32, 8, 128, 16
@@ -160,6 +166,7 @@ def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, monkeypatch):
 
 @pytest.mark.parametrize("T", [12, 30])
 def test_context_shorter_than_the_new_tokens(dev, monkeypatch, T):
+    monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", "48")
     """Invalid for the reference (ctx >= T there); every kernel gives rows whose position is
     negative a zero output (T = 12: decode kernel, T = 30: packed prefill kernel; against the
     generic kernel)."""
