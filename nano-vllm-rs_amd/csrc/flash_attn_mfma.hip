@@ -1166,7 +1166,7 @@ PagedGeom paged_geom(const PagedAttnArgs &a) {
     return g;
 }
 // Key-split factor of a paged launch: enough parts to put about one workgroup on every CU, at
-// least 8 key tiles (512 keys) per part by the longest context the tables allow, at most 8.
+// least 8 key tiles (512 keys) per part by the longest context the tables allow, at most 8 (16).
 int paged_ksplit_parts(const PagedAttnArgs &a, const PagedGeom &g) {
     if (const char *e = getenv("NVLLM_K1_KSPLIT")) {
         const int v = atoi(e);
@@ -1178,7 +1178,10 @@ int paged_ksplit_parts(const PagedAttnArgs &a, const PagedGeom &g) {
     long long parts = cus / units;
     const long long max_steps = ((long long)a.max_blocks_per_seq * 16 + kKV - 1) / kKV;
     if (parts > max_steps / 8) parts = max_steps / 8;
-    if (parts > 8) parts = 8;
+    // at most 8 parts; 16 for a handful of units (one sequence's short chunk on a long context:
+    // 1 x 32768, 16 new tokens, 78 -> 58 us), where more parts than that stopped paying
+    const long long cap = units <= 16 ? 16 : 8;
+    if (parts > cap) parts = cap;
     return parts < 1 ? 1 : (int)parts;
 }
 }  // namespace
