@@ -1012,9 +1012,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #endif
 }
 
-// Combines the P partials of every row (KSPLIT): grid = (16, pairs_max * Hu, num_seqs) with
-// Hu = Hq >> pack_shift units (kv head, head group); 16 rows of a unit per workgroup, 16 lanes x
-// 16 bytes per row.  Tile geometry and row packing as in the kernel above.
+// Combines the P partials of every row (KSPLIT): grid = (64, pairs_max * Hu, num_seqs) with
+// Hu = Hq >> pack_shift units (kv head, head group); 4 rows of a unit per workgroup, one wave per
+// row.  The wave's four 16-lane groups take every fourth part (at most kMaxParts = 16 parts, so
+// four independent 16-byte loads per lane) and meet through two shuffles.  Tile geometry and row
+// packing as in the kernel above.
+constexpr int kMaxParts = 16;
 __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
     const unsigned char *__restrict__ ws, __bf16 *__restrict__ o,
     const int32_t *__restrict__ context_lens, int Sq, int Hq, int Hkv, int max_blocks_per_seq,
@@ -1038,34 +1041,55 @@ __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
         tile_short = 2 * jr;
         tile_long = 2 * jr + 1 < num_q_tiles ? 2 * jr + 1 : 2 * jr;
     }
-    const int ur = (blockIdx.x << 4) + (threadIdx.x >> 4);
-    const int ch = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const int ur = (blockIdx.x << 2) + (threadIdx.x >> 6);  // one wave per row
+    const int grp = lane >> 4, ch = lane & 15;
     if (ur >= kQTile && tile_long == tile_short) return;
     const int rho = (ur >= kQTile ? tile_long : tile_short) * kQTile + (ur & (kQTile - 1));  // packed row
     const int row = (rho >> gsh) - pos_shift;
     if (row < 0 || row >= Sq) return;
     const int hq = (hu % Hkv) * (Hq / Hkv) + (hu / Hkv) * gp + (rho & (gp - 1));
     const unsigned char *slot0 = ws + (((size_t)b * Hu + hu) * pairs_max + J) * parts * (size_t)kSplitSlotBytes;
+    float m[kMaxParts / 4], l[kMaxParts / 4];
+    u32x4 x[kMaxParts / 4];
     float mmax = -INFINITY;
-    for (int p = 0; p < parts; ++p) {
-        const float *ml = reinterpret_cast<const float *>(slot0 + (size_t)p * kSplitSlotBytes + 2 * kQTile * kD * 2) + 2 * ur;
-        if (ml[1] > 0.0f) mmax = fmaxf(mmax, ml[0]);
+#pragma unroll
+    for (int i = 0; i < kMaxParts / 4; ++i) {
+        const int p = grp + 4 * i;
+        m[i] = -INFINITY;
+        l[i] = 0.0f;
+        x[i] = u32x4{0u, 0u, 0u, 0u};
+        if (p < parts) {
+            const unsigned char *slot = slot0 + (size_t)p * kSplitSlotBytes;
+            const float *ml = reinterpret_cast<const float *>(slot + 2 * kQTile * kD * 2) + 2 * ur;
+            m[i] = ml[0];
+            l[i] = ml[1];
+            x[i] = *reinterpret_cast<const u32x4 *>(slot + ((size_t)ur * kD + 8 * ch) * 2);
+            if (l[i] > 0.0f) mmax = fmaxf(mmax, m[i]);
+        }
     }
+    mmax = fmaxf(mmax, __shfl_xor(mmax, 16));
+    mmax = fmaxf(mmax, __shfl_xor(mmax, 32));
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float den = 0.0f;
-    for (int p = 0; p < parts; ++p) {
-        const unsigned char *slot = slot0 + (size_t)p * kSplitSlotBytes;
-        const float *ml = reinterpret_cast<const float *>(slot + 2 * kQTile * kD * 2) + 2 * ur;
-        if (!(ml[1] > 0.0f)) continue;
-        const float w = ml[1] * fast_exp2(ml[0] - mmax);
-        const u32x4 x = *reinterpret_cast<const u32x4 *>(slot + ((size_t)ur * kD + 8 * ch) * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[2 * i] += w * __builtin_bit_cast(float, x[i] << 16);
-            acc[2 * i + 1] += w * __builtin_bit_cast(float, x[i] & 0xffff0000u);
+    for (int i = 0; i < kMaxParts / 4; ++i) {
+        if (!(l[i] > 0.0f)) continue;
+        const float w = l[i] * fast_exp2(m[i] - mmax);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += w * __builtin_bit_cast(float, x[i][j] << 16);
+            acc[2 * j + 1] += w * __builtin_bit_cast(float, x[i][j] & 0xffff0000u);
         }
         den += w;
     }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+        den += __shfl_xor(den, off);
+    }
+    if (grp != 0) return;
     const float inv = den > 0.0f ? 1.0f / den : 0.0f;
     u32x4 y;
 #pragma unroll
@@ -1170,7 +1194,7 @@ PagedGeom paged_geom(const PagedAttnArgs &a) {
 int paged_ksplit_parts(const PagedAttnArgs &a, const PagedGeom &g) {
     if (const char *e = getenv("NVLLM_K1_KSPLIT")) {
         const int v = atoi(e);
-        if (v >= 1) return v > 16 ? 16 : v;
+        if (v >= 1) return v > kMaxParts ? kMaxParts : v;
     }
     const long long units = (long long)g.pairs * g.units * a.num_seqs;
     const long long cus = device_cus();
@@ -1216,7 +1240,7 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
             g.gsh);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
-        const dim3 mgrid(16, (unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
+        const dim3 mgrid(2 * kQTile / 4, (unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
         flash_attn_ksplit_merge_kernel<<<mgrid, dim3(256), 0, stream>>>(
             ws, o, a.context_lens, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.max_blocks_per_seq,
             pair_adjacent, parts, g.gsh);
