@@ -199,7 +199,8 @@ uint64_t nvllm_hash_token_block(const uint32_t *token_ids, int64_t num_tokens, i
                                 uint64_t parent_hash);
 
 /* RotaryEmbedding::new (src/model/rope.rs:42-80), host side: cos / sin tables
- * [max_seq_len, dim] in f32 (inv_freq in f64 -> f32, angle = pos * inv_freq in f32, the row is
+ * [max_seq_len, dim] in f32 (inv_freq = 1.0f32 / (theta^(2i/dim) in f64 -> f32), as rope.rs:55
+ * parses; angle = pos * inv_freq in f32, the row is
  * the half-row twice).  Odd dim -> NVLLM_ERR_CONFIG (the reference panics). */
 int nvllm_rope_cache_f32(int64_t dim, int64_t max_seq_len, double theta, float *cos_out,
                          float *sin_out);

@@ -250,8 +250,10 @@ bool rope_cache(std::size_t dim, std::size_t max_seq_len, double theta, float *c
     if (dim == 0 || (dim & 1)) return false;
     const std::size_t half = dim / 2;
     std::vector<float> inv_freq(half);
-    for (std::size_t i = 0; i < half; ++i)  // rope.rs:55-57: f64 powf, stored as f32
-        inv_freq[i] = static_cast<float>(1.0 / std::pow(theta, 2.0 * (double)i / (double)dim));
+    // rope.rs:55: `1.0 / theta.powf(..) as f32` -- `as` binds tighter than `/`: the power is taken in
+    // f64 and narrowed, the division is an f32 one
+    for (std::size_t i = 0; i < half; ++i)
+        inv_freq[i] = 1.0f / static_cast<float>(std::pow(theta, 2.0 * (double)i / (double)dim));
     for (std::size_t p = 0; p < max_seq_len; ++p)
         for (std::size_t i = 0; i < half; ++i) {
             const float f = static_cast<float>(p) * inv_freq[i];  // rope.rs:65 broadcast_mul in f32

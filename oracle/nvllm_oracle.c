@@ -430,8 +430,10 @@ int oracle_rms_norm(const float *x, const float *weight, double eps, int64_t row
     return ORACLE_OK;
 }
 
-/* src/model/rope.rs:42-80  RotaryEmbedding::new: inv_freq[i] = (1 / theta^(2i/dim)) computed in
- * f64 and stored as f32; freqs[p][i] = (p as f32) * inv_freq[i] in f32; the row is
+/* src/model/rope.rs:42-80  RotaryEmbedding::new.  rope.rs:55 reads
+ * `1.0 / theta.powf(2.0 * i as f64 / dim as f64) as f32`: `as` binds tighter than `/`, so the power
+ * is taken in f64, narrowed to f32, and the DIVISION is an f32 one (1.0f32 / x).
+ * freqs[p][i] = (p as f32) * inv_freq[i] in f32; the row is
  * cat(freqs, freqs) (so column i and i + dim/2 are equal); cos/sin taken in f32.
  * cos, sin: [max_seq_len, dim].                                                */
 int oracle_rope_cache(int64_t dim, int64_t max_seq_len, double theta, float *cos_out,
@@ -440,7 +442,7 @@ int oracle_rope_cache(int64_t dim, int64_t max_seq_len, double theta, float *cos
     const int64_t half = dim / 2;
     for (int64_t p = 0; p < max_seq_len; ++p)
         for (int64_t i = 0; i < half; ++i) {
-            const float inv_freq = (float)(1.0 / pow(theta, 2.0 * (double)i / (double)dim));
+            const float inv_freq = 1.0f / (float)pow(theta, 2.0 * (double)i / (double)dim);
             const float f = (float)p * inv_freq;
             const float c = cosf(f), sn = sinf(f);
             cos_out[p * dim + i] = c;

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
-from helpers import bf16_randn, make_paged_case  # noqa: E402
+from helpers import bf16_randn, hashed_bf16, make_paged_case  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -68,6 +68,22 @@ def paged_cases():
     cases["shared_prefix_T4"] = dict(q=bits(q), kc=bits(kc), vc=bits(vc), table=tab,
                                      ctx=np.array([100, 83]), out=np.concatenate(outs, 0))
     return cases
+
+
+def paged_hashed_cases():
+    """block 16, 32 Q / 8 KV heads, D 128, ONE sequence of ctx 2048, T = 1 (one sequence
+    of BASELINE config 3).  Its 2 x 4 MiB of K/V are not committed: inputs come from
+    helpers.hashed_bf16 (integer hash of the element index; stream ids below), only the table and
+    the oracle's output are stored."""
+    nb, bs, Hq, Hkv, D, ctx = 160, 16, 32, 8, 128, 2048
+    rng = np.random.default_rng(201)
+    table = rng.permutation(nb)[:ctx // bs].astype(np.int32)
+    kc = hashed_bf16((nb, bs, Hkv, D), 1)
+    vc = hashed_bf16((nb, bs, Hkv, D), 2)
+    q = hashed_bf16((1, 1, Hq, D), 3)
+    out = oracle.paged_attention(q, kc, vc, table.tolist(), bs, ctx, Hq, Hkv, D, 1 / math.sqrt(D))
+    return {"qwen4b_ctx2048_T1": dict(streams=np.array([1, 2, 3]), shape=np.array([nb, bs, Hq, Hkv, D]),
+                                      table=table, ctx=np.array(ctx), out=out)}
 
 
 def kv_write_cases():
@@ -132,11 +148,14 @@ def norm_rope_cases():
     cases = {}
     rng = np.random.default_rng(500)
     for name, n, Hq, Hkv, D, nb, bs, max_pos, theta in [("d128_gqa", 19, 8, 2, 128, 4, 16, 256, 1e6),
-                                                        ("d64_mha", 7, 4, 4, 64, 2, 8, 64, 1e4)]:
+                                                        ("d64_mha", 7, 4, 4, 64, 2, 8, 64, 1e4),
+                                                        # positions near 32k: where rope.rs:55's f32
+                                                        # division shows (a f64 one moves cos/sin by 4e-4)
+                                                        ("d128_longpos", 11, 4, 2, 128, 2, 16, 32768, 1e6)]:
         q, k, v = bf16_randn(rng, (n, Hq, D)), bf16_randn(rng, (n, Hkv, D)), bf16_randn(rng, (n, Hkv, D))
         qw = oracle.bf16_round(1.0 + 0.25 * bf16_randn(rng, (D,)))
         kw = oracle.bf16_round(1.0 + 0.25 * bf16_randn(rng, (D,)))
-        pos = rng.integers(0, max_pos, size=n).astype(np.int32)
+        pos = rng.integers(max_pos - max_pos // 8 if max_pos > 4096 else 0, max_pos, size=n).astype(np.int32)
         slots = rng.permutation(nb * bs)[:n].astype(np.int64)
         cos, sin = oracle.rope_cache(D, max_pos, theta)
         cos, sin = oracle.bf16_round(cos), oracle.bf16_round(sin)
@@ -205,6 +224,8 @@ def main():
                         **{"%s/%s" % (c, k): v for c, d in flash_cases().items() for k, v in d.items()})
     np.savez_compressed(os.path.join(OUT, "paged.npz"),
                         **{"%s/%s" % (c, k): v for c, d in paged_cases().items() for k, v in d.items()})
+    np.savez_compressed(os.path.join(OUT, "paged_hashed.npz"),
+                        **{"%s/%s" % (c, k): v for c, d in paged_hashed_cases().items() for k, v in d.items()})
     np.savez_compressed(os.path.join(OUT, "kv_write.npz"),
                         **{"%s/%s" % (c, k): v for c, d in kv_write_cases().items() for k, v in d.items()})
     np.savez_compressed(os.path.join(OUT, "norm_rope.npz"),
@@ -213,7 +234,7 @@ def main():
         json.dump(allocator_traces(), f)
     with open(os.path.join(OUT, "scheduler.json"), "w") as f:
         json.dump(scheduler_traces(), f)
-    for n in ("flash.npz", "paged.npz", "kv_write.npz", "norm_rope.npz", "allocator.json", "scheduler.json"):
+    for n in ("flash.npz", "paged.npz", "paged_hashed.npz", "kv_write.npz", "norm_rope.npz", "allocator.json", "scheduler.json"):
         print(n, os.path.getsize(os.path.join(OUT, n)))
 
 

@@ -81,3 +81,22 @@ def oracle_paged_batch(q, kc, vc, tables, ctx_lens, block_size, scale):
         outs.append(oracle.paged_attention(q[i:i + 1], kc, vc, tables[i][:max(nblk, 1)], block_size,
                                            ctx_lens[i], Hq, Hkv, D, scale))
     return np.concatenate(outs, axis=0)
+
+
+def hashed_bf16(shape, stream):
+    """Deterministic ~N(0,1) values rounded to bf16 (as float32), made by a counter-based
+    integer hash (splitmix64 of stream * 2^40 + index; the sum of the four 16-bit fields is
+    Irwin-Hall, scaled to unit variance).  Pure uint64 arithmetic, so a fixture can commit the
+    stream id instead of megabytes of inputs and any numpy reproduces the same bits."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + (np.uint64(stream) << np.uint64(40))
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    s = np.zeros(n, dtype=np.float64)
+    for k in range(4):
+        s += ((z >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.float64)
+    x = (s / 65536.0 - 2.0) * np.sqrt(3.0)
+    return oracle.bf16_round(x.astype(np.float32)).reshape(shape)

@@ -12,7 +12,7 @@ import torch
 
 import nano_vllm_rs_amd as nv
 import oracle
-from helpers import assert_attention_close
+from helpers import assert_attention_close, hashed_bf16
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -56,6 +56,23 @@ def test_oracle_reproduces_paged_goldens():
             out = oracle.paged_attention(q[i:i + 1], kc, vc, tabs[i][:n], bs, int(ctxs[i]),
                                          q.shape[2], Hkv, D, 1 / math.sqrt(D))
             assert np.abs(out - c["out"][i:i + 1]).max() < 1e-5, name
+
+
+def _hashed_case(c):
+    nb, bs, Hq, Hkv, D = (int(x) for x in c["shape"])
+    sk, sv, sq = (int(x) for x in c["streams"])
+    return (hashed_bf16((1, 1, Hq, D), sq), hashed_bf16((nb, bs, Hkv, D), sk),
+            hashed_bf16((nb, bs, Hkv, D), sv), bs, Hq, Hkv, D)
+
+
+def test_oracle_reproduces_hashed_paged_golden():
+    # SURVEY 8c's ctx-2048 vector (one sequence of config 3); inputs regenerated from stream ids
+    for name, c in _load("paged_hashed.npz").items():
+        q, kc, vc, bs, Hq, Hkv, D = _hashed_case(c)
+        assert abs(float(kc.std()) - 1.0) < 0.02 and abs(float(kc.mean())) < 0.01
+        out = oracle.paged_attention(q, kc, vc, c["table"].tolist(), bs, int(c["ctx"]), Hq, Hkv, D,
+                                     1 / math.sqrt(D))
+        assert np.abs(out - c["out"]).max() < 1e-5, name
 
 
 def test_oracle_reproduces_kv_write_goldens():
@@ -175,6 +192,23 @@ def test_gpu_paged_goldens(dev):
         tabs = torch.from_numpy(np.atleast_2d(c["table"]).astype(np.int32)).to(dev)
         ctxs = torch.from_numpy(np.atleast_1d(c["ctx"]).astype(np.int32)).to(dev)
         out = nv.paged_attention_batched(q, kc, vc, tabs, ctxs, 1 / math.sqrt(D))
+        assert_attention_close(out.float().cpu().numpy(), c["out"])
+
+
+@pytest.mark.gpu
+def test_gpu_hashed_paged_golden(dev):
+    """ctx 2048, 32Q/8KV, D128, block 16, T=1 against the committed oracle output; blocks outside
+    the table are NaN so a wrong block id cannot pass."""
+    for name, c in _load("paged_hashed.npz").items():
+        q, kc, vc, bs, Hq, Hkv, D = _hashed_case(c)
+        dead = np.ones(kc.shape[0], bool)
+        dead[c["table"]] = False
+        kc[dead] = np.nan
+        vc[dead] = np.nan
+        to = lambda a: torch.from_numpy(a).to(dev, torch.bfloat16)
+        out = nv.paged_attention_batched(to(q), to(kc), to(vc), torch.from_numpy(c["table"][None]).to(dev),
+                                         torch.tensor([int(c["ctx"])], dtype=torch.int32, device=dev),
+                                         1 / math.sqrt(D))
         assert_attention_close(out.float().cpu().numpy(), c["out"])
 
 

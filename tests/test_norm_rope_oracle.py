@@ -65,3 +65,23 @@ def test_host_rope_cache_is_bit_identical_to_oracle(dim, n, theta):
     ocos, osin = oracle.rope_cache(dim, n, theta)
     assert np.array_equal(cos, ocos) and np.array_equal(sin, osin)
     assert nv.capi.lib().nvllm_rope_cache_f32(5, 8, theta, cos.ctypes.data, sin.ctypes.data) == nv.capi.NVLLM_ERR_CONFIG
+
+
+def test_inv_freq_division_is_f32_at_long_positions():
+    """rope.rs:55 `1.0 / theta.powf(..) as f32`: the cast binds tighter than the division, so
+    inv_freq = 1.0f32 / (pow as f32).  A f64 division rounded afterwards differs by one ulp in 25
+    of the 64 frequencies at theta = 1e6, dim = 128 -- invisible at small positions, up to 4e-4 in
+    cos/sin at position 32767.  Pin the oracle (and, through the bit-equality test above, the host
+    table) on an independent numpy evaluation of the f32-division form at that position."""
+    dim, theta, pos = 128, 1e6, 32767
+    i = np.arange(dim // 2)
+    powf = np.float32(theta ** (2.0 * i / dim))                 # f64 power, narrowed
+    inv32 = np.float32(1.0) / powf                              # the reference's arithmetic
+    inv64 = (1.0 / theta ** (2.0 * i / dim)).astype(np.float32)  # the misreading
+    assert (inv32 != inv64).sum() >= 8                          # the two really differ
+    cos, sin = oracle.rope_cache(dim, pos + 1, theta)
+    ang = (np.float32(pos) * inv32).astype(np.float64)
+    assert np.abs(cos[pos, :dim // 2] - np.cos(ang)).max() < 1e-6
+    assert np.abs(sin[pos, :dim // 2] - np.sin(ang)).max() < 1e-6
+    ang_wrong = (np.float32(pos) * inv64).astype(np.float64)
+    assert np.abs(np.cos(ang_wrong) - np.cos(ang)).max() > 1e-4  # what the f64 division would cost
