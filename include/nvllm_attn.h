@@ -16,8 +16,15 @@
  *                     (src/core/kv_cache.rs:75-95)
  *     GQA is native: q head h reads kv head h / (num_heads / num_kv_heads)
  *     (src/attention/flash.rs:147-154, src/attention/paged.rs:326-338).
- *   - Launches are asynchronous on `stream` (NULL = the default stream); no
- *     entry point synchronises the device or allocates device memory.
+ *   - Launches are asynchronous on `stream` (NULL = the default stream) and no
+ *     entry point allocates device memory.  No entry point synchronises, WITH
+ *     THREE EXCEPTIONS, the ones that take a HOST array the way the reference's
+ *     API does and must copy it to the device out of pageable memory:
+ *     nvllm_batch_upload, nvllm_paged_attention_seq and nvllm_write_kv_to_cache
+ *     each call hipStreamSynchronize(stream) once after their upload.  These
+ *     three therefore cannot run on a capturing stream; everything else is
+ *     HIP-graph capturable (the batched kernels take device arrays only).
+ *     nvllm_synchronize is the explicit device-wide wait.
  *   - Return value: NVLLM_OK or a negative nvllm_status.  The message of the
  *     last failure on the calling thread is nvllm_get_last_error().
  *   - Host-logic entries (block tables, allocator, hashing) are pure CPU code
@@ -113,7 +120,11 @@ int nvllm_paged_attn_f32(const void *q, const void *k_cache, const void *v_cache
                          nvllm_stream_t stream);
 
 /* Bytes of split-K scratch nvllm_paged_attn_* needs for this launch shape
- * (an upper bound over all context lengths <= max_blocks_per_seq*block_size). */
+ * (an upper bound over all context lengths <= max_blocks_per_seq*block_size).
+ * The launch takes its split decision from the same arguments by the same
+ * arithmetic; a workspace smaller than this value (or NULL when it is > 0, or
+ * not 16-byte aligned) is rejected with NVLLM_ERR_CONFIG -- never a silently
+ * different launch. */
 size_t nvllm_paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,
                                         int num_kv_heads, int head_dim, int block_size,
                                         int max_blocks_per_seq);
@@ -138,6 +149,20 @@ int nvllm_reshape_and_cache_f32(const void *key, const void *value, void *k_cach
                                 const int64_t *slot_mapping, int64_t num_tokens, int num_kv_heads,
                                 int head_dim, int block_size, int64_t num_cache_blocks,
                                 nvllm_stream_t stream);
+
+/* LayerKVCache::gather_keys / gather_values (src/core/kv_cache.rs:123-144, an
+ * index_select over dim 0): out[i, :, :, :] = cache[block_ids[i], :, :, :].
+ *   cache      [num_cache_blocks, block_size, num_kv_heads, head_dim]
+ *   block_ids  int32 [num_ids] ON DEVICE (the reference casts usize -> u32)
+ *   out        [num_ids, block_size, num_kv_heads, head_dim]
+ * num_ids == 0 -> NVLLM_ERR_CONFIG "block_ids cannot be empty" (kv_cache.rs:124).
+ * An id outside the pool cannot be reported without a sync (the reference's
+ * index_select fails): that block of `out` is zero-filled.  The attention
+ * kernels never call this -- they read through the block table; it is the
+ * reference's contiguous view for callers that want one.  dtype 0 bf16, 1 f32. */
+int nvllm_gather_cache_blocks(const void *cache, const int32_t *block_ids, int64_t num_ids, void *out,
+                              int64_t num_cache_blocks, int block_size, int num_kv_heads,
+                              int head_dim, int dtype, nvllm_stream_t stream);
 
 /* Producer side of the paged cache in one pass: per-head RMSNorm of Q and K, RoPE, then K (rotated)
  * and V go into their cache slots -- no intermediate tensors.
@@ -181,6 +206,28 @@ const char *nvllm_get_last_error(void);
 
 /* Replaces: flash_attention_synchronize (kernels/flash_attn_fwd.cu:548-551): 0 / -1. */
 int nvllm_synchronize(void);
+
+/* KVCacheConfig::layer_cache_size_bytes / total_cache_size_bytes
+ * (src/core/kv_cache.rs:62-70): bytes of ONE layer's K (or V) cache
+ * [num_blocks, block_size, num_kv_heads, head_dim], and of all layers' K and V.
+ * dtype: 0 = bf16, 1 = f32 (the reference's default, kv_cache.rs:51).  -1 on a
+ * negative dimension or unknown dtype. */
+int64_t nvllm_kv_cache_layer_bytes(int64_t num_blocks, int64_t block_size, int64_t num_kv_heads,
+                                   int64_t head_dim, int dtype);
+int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64_t num_kv_heads,
+                                   int64_t head_dim, int64_t num_layers, int dtype);
+
+/* Test / tuning hook, no counterpart in the reference: pins one launch decision
+ * that is otherwise taken from the launch shape.  `name` is one of
+ * NVLLM_PAGED_MAX_ROWS, NVLLM_PAGED_SPLITS, NVLLM_PAGED_WAVE_TARGET,
+ * NVLLM_PAGED_NT, NVLLM_PAGED_HPB, NVLLM_PAGED_FLASH, NVLLM_K1_PAIRING (0
+ * balanced / 1 adjacent), NVLLM_K1_PACK, NVLLM_K1_KSPLIT.  Environment variables
+ * of the same names seed the values once, at first use; no launch reads the
+ * environment.  Process-wide: nvllm_paged_attn_workspace_bytes and the launch
+ * both see the value in force when they are called.  _reset restores the
+ * environment's values. */
+int nvllm_debug_set_policy(const char *name, int value);
+void nvllm_debug_reset_policy(void);
 
 /* Device inventory used by the sharded launcher and the bench. */
 int nvllm_device_count(void);

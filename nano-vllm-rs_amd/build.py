@@ -15,6 +15,7 @@ SOURCES = [
     "nvllm_host.cpp",
     "nvllm_sched.cpp",
     "capi.cpp",
+    "launch_policy.cpp",
     "reshape_and_cache.hip",
     "qk_norm_rope_cache.hip",
     "paged_attn.hip",

@@ -38,6 +38,11 @@ SIGNATURES = {
     "nvllm_rope_cache_f32": (_i, [_i64, _i64, _d, _vp, _vp]),
     "nvllm_get_last_error": (_c.c_char_p, []),
     "nvllm_synchronize": (_i, []),
+    "nvllm_gather_cache_blocks": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "nvllm_kv_cache_layer_bytes": (_i64, [_i64, _i64, _i64, _i64, _i]),
+    "nvllm_kv_cache_total_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _i]),
+    "nvllm_debug_set_policy": (_i, [_c.c_char_p, _i]),
+    "nvllm_debug_reset_policy": (None, []),
     "nvllm_device_count": (_i, []),
     "nvllm_set_device": (_i, [_i]),
     "nvllm_compute_num_blocks": (_i64, [_i64, _i64]),

@@ -225,13 +225,24 @@ class KVCacheConfig:
         self.dtype = dtype
         return self
 
-    def layer_cache_size_bytes(self):
+    def _dtype_code(self):
         import torch
-        elt = torch.empty((), dtype=self.dtype).element_size()
-        return self.num_blocks * self.block_size * self.num_kv_heads * self.head_dim * elt
+        codes = {torch.bfloat16: 0, torch.float32: 1}
+        if self.dtype not in codes:
+            raise ConfigError(capi.NVLLM_ERR_UNSUPPORTED, "dtype must be bfloat16 or float32")
+        return codes[self.dtype]
+
+    def layer_cache_size_bytes(self):
+        """kv_cache.rs:62-65 (nvllm_kv_cache_layer_bytes)."""
+        return int(capi.lib().nvllm_kv_cache_layer_bytes(self.num_blocks, self.block_size,
+                                                         self.num_kv_heads, self.head_dim,
+                                                         self._dtype_code()))
 
     def total_cache_size_bytes(self):
-        return self.layer_cache_size_bytes() * self.num_layers * 2
+        """kv_cache.rs:68-70 (nvllm_kv_cache_total_bytes)."""
+        return int(capi.lib().nvllm_kv_cache_total_bytes(self.num_blocks, self.block_size,
+                                                         self.num_kv_heads, self.head_dim,
+                                                         self.num_layers, self._dtype_code()))
 
 
 class LayerKVCache:
@@ -250,6 +261,28 @@ class LayerKVCache:
 
     def value_cache(self):
         return self._value_cache
+
+    def _gather(self, cache, block_ids):
+        import torch
+        if len(block_ids) == 0:  # kv_cache.rs:124-126
+            raise ConfigError(capi.NVLLM_ERR_CONFIG, "block_ids cannot be empty")
+        c = self.config
+        ids = torch.tensor([int(b) for b in block_ids], dtype=torch.int32, device=cache.device)
+        out = torch.empty((len(block_ids), c.block_size, c.num_kv_heads, c.head_dim), dtype=c.dtype,
+                          device=cache.device)
+        st = torch.cuda.current_stream(cache.device).cuda_stream
+        check(capi.lib().nvllm_gather_cache_blocks(cache.data_ptr(), ids.data_ptr(), len(block_ids),
+                                                   out.data_ptr(), c.num_blocks, c.block_size,
+                                                   c.num_kv_heads, c.head_dim, c._dtype_code(), st))
+        return out
+
+    def gather_keys(self, block_ids):
+        """kv_cache.rs:123-132 -> [len(block_ids), block_size, Hkv, D]."""
+        return self._gather(self._key_cache, block_ids)
+
+    def gather_values(self, block_ids):
+        """kv_cache.rs:135-144."""
+        return self._gather(self._value_cache, block_ids)
 
 
 class KVCache:
@@ -271,6 +304,14 @@ class KVCache:
 
     def device(self):
         return self._device
+
+    def gather_keys_all_layers(self, block_ids):
+        """kv_cache.rs:251-256"""
+        return [l.gather_keys(block_ids) for l in self.layers]
+
+    def gather_values_all_layers(self, block_ids):
+        """kv_cache.rs:259-264"""
+        return [l.gather_values(block_ids) for l in self.layers]
 
 
 class BatchMetadata:

@@ -98,6 +98,20 @@ int paged_common(kernels::DType dt, const void *q, const void *k_cache, const vo
                                       block_size, max_blocks_per_seq) &&
         !(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(out)))
         return fail(ErrorKind::Config, "paged_attn: tensors must be 16-byte aligned");
+    // the split decision is a function of the launch shape (and the launch policy) alone, and
+    // nvllm_paged_attn_workspace_bytes is that same function: a smaller workspace is a caller
+    // error, not a reason to launch differently
+    const size_t need = dt == kernels::DType::BF16
+                            ? kernels::paged_attn_workspace_bytes(num_seqs, num_new_tokens, num_heads,
+                                                                  num_kv_heads, head_dim, block_size,
+                                                                  max_blocks_per_seq)
+                            : 0;
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(ErrorKind::Config, "paged_attn: workspace of " + std::to_string(workspace ? workspace_bytes : 0) +
+                                           " bytes, this launch shape needs " + std::to_string(need) +
+                                           " (nvllm_paged_attn_workspace_bytes)");
+    if (need > 0 && !aligned16(workspace))
+        return fail(ErrorKind::Config, "paged_attn: workspace must be 16-byte aligned");
     return hip_status(kernels::launch_paged_attn(dt, a, as_stream(stream)), "paged_attn launch");
 }
 
@@ -213,6 +227,23 @@ int nvllm_reshape_and_cache_f32(const void *key, const void *value, void *k_cach
                           head_dim, block_size, num_cache_blocks, stream);
 }
 
+int nvllm_gather_cache_blocks(const void *cache, const int32_t *block_ids, int64_t num_ids, void *out,
+                              int64_t num_cache_blocks, int block_size, int num_kv_heads,
+                              int head_dim, int dtype, nvllm_stream_t stream) {
+    if (num_ids <= 0)  // kv_cache.rs:124-126
+        return fail(ErrorKind::Config, "block_ids cannot be empty");
+    if (!cache || !block_ids || !out) return fail(ErrorKind::Null, "gather_cache_blocks: null pointer");
+    if (num_cache_blocks <= 0 || block_size <= 0 || num_kv_heads <= 0 || head_dim <= 0)
+        return fail(ErrorKind::Config, "gather_cache_blocks: negative or zero dimension");
+    if (dtype != 0 && dtype != 1) return fail(ErrorKind::Unsupported, "gather_cache_blocks: dtype");
+    const int64_t block_bytes = (int64_t)block_size * num_kv_heads * head_dim * (dtype == 0 ? 2 : 4);
+    if (block_bytes % 16 != 0 || !aligned16(cache) || !aligned16(out))
+        return fail(ErrorKind::Unsupported, "gather_cache_blocks: blocks must be 16-byte multiples, 16-byte aligned");
+    return hip_status(kernels::launch_gather_blocks(cache, block_ids, out, num_ids, block_bytes,
+                                                    num_cache_blocks, as_stream(stream)),
+                      "gather_cache_blocks launch");
+}
+
 const char *nvllm_get_last_error(void) { return nvllm::last_error_message(); }
 
 int nvllm_synchronize(void) {
@@ -222,6 +253,28 @@ int nvllm_synchronize(void) {
         return -1;
     }
     return 0;
+}
+
+int nvllm_debug_set_policy(const char *name, int value) {
+    if (!kernels::set_launch_policy(name, value))
+        return fail(ErrorKind::Config, std::string("unknown launch-policy name: ") + (name ? name : "(null)"));
+    return NVLLM_OK;
+}
+
+void nvllm_debug_reset_policy(void) { kernels::reset_launch_policy(); }
+
+int64_t nvllm_kv_cache_layer_bytes(int64_t num_blocks, int64_t block_size, int64_t num_kv_heads,
+                                   int64_t head_dim, int dtype) {
+    if (num_blocks < 0 || block_size < 0 || num_kv_heads < 0 || head_dim < 0 || (dtype != 0 && dtype != 1))
+        return -1;
+    return num_blocks * block_size * num_kv_heads * head_dim * (dtype == 0 ? 2 : 4);  // kv_cache.rs:62-65
+}
+
+int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64_t num_kv_heads,
+                                   int64_t head_dim, int64_t num_layers, int dtype) {
+    const int64_t layer = nvllm_kv_cache_layer_bytes(num_blocks, block_size, num_kv_heads, head_dim, dtype);
+    if (layer < 0 || num_layers < 0) return -1;
+    return layer * num_layers * 2;  // kv_cache.rs:68-70: K and V
 }
 
 int nvllm_device_count(void) {

@@ -1099,20 +1099,6 @@ __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
 
 }  // namespace
 
-namespace {
-int device_cus() {
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        num_cus = n;
-    }
-    return num_cus;
-}
-}  // namespace
-
 bool flash_attn_mfma_supported(const FlashAttnArgs &a) {
     if (a.head_dim != kD) return false;
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
@@ -1128,7 +1114,7 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     const int pairs = (num_q_tiles + 1) / 2;
     // adjacent pairing once there are at least two workgroups per CU (MI355X: 256 CUs)
     int pair_adjacent = (int64_t)pairs * a.num_heads * a.batch >= (int64_t)2 * device_cus();
-    if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
+    if (launch_policy().k1_pairing >= 0) pair_adjacent = launch_policy().k1_pairing;
     const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.batch), block(64 * kWaves);
     const float scale_log2e = a.softmax_scale * 1.4426950408889634f;
     auto q = static_cast<const __bf16 *>(a.q);
@@ -1169,13 +1155,8 @@ namespace {
 // us); long ones gain a little from the shorter diagonal (NVLLM_K1_PACK=0 switches it off).
 int paged_pack_shift(const PagedAttnArgs &a) {
     const int G = a.num_heads / a.num_kv_heads;
-    int gsh = G == 2 ? 1 : (G == 4 ? 2 : (G == 8 ? 3 : 0));
-    if (const char *e = getenv("NVLLM_K1_PACK")) {
-        const int v = atoi(e);
-        if (v == 0) return 0;
-        if (v > 0) return gsh;
-    }
-    return gsh;
+    const int gsh = G == 2 ? 1 : (G == 4 ? 2 : (G == 8 ? 3 : 0));
+    return launch_policy().k1_pack == 0 ? 0 : gsh;
 }
 struct PagedGeom {
     int gsh, units, num_q_tiles, pairs;
@@ -1192,10 +1173,7 @@ PagedGeom paged_geom(const PagedAttnArgs &a) {
 // Key-split factor of a paged launch: enough parts to put about one workgroup on every CU, at
 // least 8 key tiles (512 keys) per part by the longest context the tables allow, at most 8 (16).
 int paged_ksplit_parts(const PagedAttnArgs &a, const PagedGeom &g) {
-    if (const char *e = getenv("NVLLM_K1_KSPLIT")) {
-        const int v = atoi(e);
-        if (v >= 1) return v > kMaxParts ? kMaxParts : v;
-    }
+    if (const int v = launch_policy().k1_ksplit; v >= 1) return v > kMaxParts ? kMaxParts : v;
     const long long units = (long long)g.pairs * g.units * a.num_seqs;
     const long long cus = device_cus();
     if (units * 2 > cus) return 1;
@@ -1220,7 +1198,7 @@ size_t flash_attn_paged_workspace_bytes(const PagedAttnArgs &a) {
 hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     const PagedGeom g = paged_geom(a);
     int pair_adjacent = (int64_t)g.pairs * g.units * a.num_seqs >= (int64_t)2 * device_cus();
-    if (const char *e = getenv("NVLLM_K1_PAIRING")) pair_adjacent = e[0] == 'a';
+    if (launch_policy().k1_pairing >= 0) pair_adjacent = launch_policy().k1_pairing;
     const dim3 block(64 * kWaves);
     const float scale_log2e = a.scale * 1.4426950408889634f;
     const unsigned chunks = (unsigned)(a.num_cache_blocks * 16 * a.num_kv_heads * 16);
@@ -1230,8 +1208,10 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     auto o = static_cast<__bf16 *>(a.out);
     const int parts = paged_ksplit_parts(a, g);
     const size_t need = (size_t)a.num_seqs * g.units * g.pairs * parts * kSplitSlotBytes;
-    if (parts > 1 && a.workspace && a.workspace_bytes >= need &&
-        (reinterpret_cast<uintptr_t>(a.workspace) & 15u) == 0) {
+    if (parts > 1) {
+        // checked against flash_attn_paged_workspace_bytes by the C ABI (same policy, same arithmetic)
+        if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15u) != 0)
+            return hipErrorInvalidValue;
         auto ws = static_cast<unsigned char *>(a.workspace);
         const dim3 grid((unsigned)(g.pairs * g.units), (unsigned)a.num_seqs, (unsigned)parts);
         flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(

@@ -264,6 +264,16 @@ bool rope_cache(std::size_t dim, std::size_t max_seq_len, double theta, float *c
     return true;
 }
 
+void BatchMetadata::truncate(std::size_t num_seqs) {
+    if (num_seqs >= context_lens_.size()) return;
+    const std::size_t tokens = static_cast<std::size_t>(query_start_[num_seqs]);
+    block_tables_.resize(num_seqs * max_blocks_);
+    context_lens_.resize(num_seqs);
+    slot_mapping_.resize(tokens);
+    positions_.resize(tokens);
+    query_start_.resize(num_seqs + 1);
+}
+
 void BatchMetadata::clear() {
     block_tables_.clear();
     context_lens_.clear();
@@ -287,11 +297,11 @@ Error BatchMetadata::add_sequence(const BlockTable &table, std::size_t context_l
     if (ids.size() > max_blocks_)
         return Error{ErrorKind::Config, "batch: block table longer than max_blocks_per_seq"};
     if (context_len > 0x7fffffffu) return Error{ErrorKind::Config, "batch: context_len too large"};
-    for (std::size_t i = 0; i < max_blocks_; ++i) {
-        const std::size_t id = i < ids.size() ? ids[i] : 0;
+    // every check comes before the first push_back: a rejected sequence leaves the batch untouched
+    for (std::size_t id : ids)
         if (id > 0x7fffffffu) return Error{ErrorKind::Config, "batch: block id exceeds int32"};
-        block_tables_.push_back(static_cast<std::int32_t>(id));
-    }
+    for (std::size_t i = 0; i < max_blocks_; ++i)
+        block_tables_.push_back(static_cast<std::int32_t>(i < ids.size() ? ids[i] : 0));
     context_lens_.push_back(static_cast<std::int32_t>(context_len));
     for (std::size_t p = context_len - num_new_tokens; p < context_len; ++p) {  // block.rs:272-279
         slot_mapping_.push_back(static_cast<std::int64_t>(ids[p / bs] * bs + p % bs));

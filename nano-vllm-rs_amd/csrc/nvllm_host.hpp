@@ -121,6 +121,8 @@ class BatchMetadata {
         query_start_.push_back(0);
     }
     void clear();
+    // drop every sequence after the first num_seqs (roll-back of a partly filled step)
+    void truncate(std::size_t num_seqs);
     // context_len tokens are in the cache after this step, the last num_new_tokens of them are
     // new.  Errors (Config): more new tokens than context, context beyond the table's blocks
     // (the reference's narrow() fails there, paged.rs:150), table longer than max_blocks_per_seq.

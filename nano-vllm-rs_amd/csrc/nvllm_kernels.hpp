@@ -11,11 +11,38 @@ namespace kernels {
 
 enum class DType : int { BF16 = 0, F32 = 1 };
 
+// Launch-policy overrides (launch_policy.cpp): test and tuning hooks that pin a decision the
+// launchers otherwise take from the launch shape.  The NVLLM_* environment is read ONCE, on first
+// use; afterwards only nvllm_debug_set_policy() changes a value, so that
+// nvllm_paged_attn_workspace_bytes() and the launch always see the same policy and no launch reads the
+// environment.  -1 / 0 = "decide from the shape" as noted per field.
+struct LaunchPolicy {
+    int paged_max_rows;     // NVLLM_PAGED_MAX_ROWS: > 0 pins the decode kernel's query-row limit
+    int paged_splits;       // NVLLM_PAGED_SPLITS: > 0 forces the split-K factor
+    int paged_wave_target;  // NVLLM_PAGED_WAVE_TARGET: (seq, kv head, split) waves aimed at (2048)
+    int paged_nt;           // NVLLM_PAGED_NT: 0 / 1 non-temporal K/V loads, -1 by reach
+    int paged_hpb;          // NVLLM_PAGED_HPB: 1, 2, 4, 8 kv heads per workgroup, 0 by grid size
+    int paged_flash;        // NVLLM_PAGED_FLASH: 0 keeps long launches off the prefill kernel
+    int k1_pairing;         // NVLLM_K1_PAIRING: 0 balanced ('b'), 1 adjacent ('a'), -1 by grid size
+    int k1_pack;            // NVLLM_K1_PACK: 0 no head packing, -1 / 1 pack when the group allows
+    int k1_ksplit;          // NVLLM_K1_KSPLIT: > 0 forces the key-split part count
+};
+const LaunchPolicy &launch_policy();
+// name = the environment variable's name; false if unknown
+bool set_launch_policy(const char *name, int value);
+void reset_launch_policy();  // back to the environment's values
+// compute units of the CURRENT device (cached per device id)
+int device_cus();
+
 // K4: reshape_and_cache.hip
 hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_cache,
                                     void *v_cache, const int64_t *slot_mapping,
                                     int64_t num_tokens, int64_t row_bytes, int64_t num_slots,
                                     hipStream_t stream);
+
+// LayerKVCache::gather_keys / gather_values: out[i] = cache[ids[i]] (reshape_and_cache.hip)
+hipError_t launch_gather_blocks(const void *cache, const int32_t *ids, void *out, int64_t num_ids,
+                                int64_t block_bytes, int64_t num_cache_blocks, hipStream_t stream);
 
 // K5: qk_norm_rope_cache.hip
 struct QkNormRopeCacheArgs {

@@ -282,26 +282,38 @@ void Scheduler::reset() {  // :504-511
     arrival_counter_ = 0;
 }
 
+// Both fill_* helpers are all-or-nothing: on an error the batch is cut back to what it held on
+// entry, so a later sequence's failure cannot leave a half-filled step behind.
 Error Scheduler::fill_decode_batch(const SchedulerOutputs &out, BatchMetadata *batch) const {
+    const std::size_t entry = batch->num_seqs();
     for (SequenceId id : out.decode_sequences) {
         const Sequence *seq = get_sequence(id);
-        if (!seq) return Error{ErrorKind::Config, "Sequence " + std::to_string(id) + " not found"};
-        const Error e = batch->add_sequence(seq->block_table(), seq->total_len(), 1);
-        if (!e.ok()) return e;
+        Error e = seq ? batch->add_sequence(seq->block_table(), seq->total_len(), 1)
+                      : Error{ErrorKind::Config, "Sequence " + std::to_string(id) + " not found"};
+        if (!e.ok()) {
+            batch->truncate(entry);
+            return e;
+        }
     }
     return Error{};
 }
 
 Error Scheduler::fill_prefill_batch(const SchedulerOutputs &out, std::size_t num_new_tokens,
                                     BatchMetadata *batch, std::vector<SequenceId> *added) const {
+    const std::size_t entry = batch->num_seqs();
+    const std::size_t added_entry = added ? added->size() : 0;
     for (SequenceId id : out.prefill_sequences) {
         const auto it = out.prefill_chunk_sizes.find(id);
         if (it == out.prefill_chunk_sizes.end() || it->second != num_new_tokens) continue;
         const Sequence *seq = get_sequence(id);
-        if (!seq) return Error{ErrorKind::Config, "Sequence " + std::to_string(id) + " not found"};
-        const Error e = batch->add_sequence(seq->block_table(), seq->num_prefilled_tokens() + num_new_tokens,
-                                            num_new_tokens);
-        if (!e.ok()) return e;
+        Error e = seq ? batch->add_sequence(seq->block_table(), seq->num_prefilled_tokens() + num_new_tokens,
+                                            num_new_tokens)
+                      : Error{ErrorKind::Config, "Sequence " + std::to_string(id) + " not found"};
+        if (!e.ok()) {
+            batch->truncate(entry);
+            if (added) added->resize(added_entry);
+            return e;
+        }
         if (added) added->push_back(id);
     }
     return Error{};

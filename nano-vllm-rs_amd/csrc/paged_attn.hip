@@ -559,12 +559,6 @@ __global__ __launch_bounds__(64) void paged_attn_generic_kernel(
     }
 }
 
-int env_int(const char *name, int dflt) {
-    const char *s = std::getenv(name);
-    if (!s || !*s) return dflt;
-    return std::atoi(s);
-}
-
 template <int NQT, int HPB>
 void launch_fast(const PagedAttnArgs &a, int splits, int bps, float *ws_o, float *ws_ml,
                  bool nt, hipStream_t stream) {
@@ -593,7 +587,7 @@ bool paged_attn_fast_path(DType dt, int num_seqs, int T, int Hq, int Hkv, int D,
     if (dt != DType::BF16 || D != kD || block_size != kBS) return false;
     if (Hkv <= 0 || Hq % Hkv != 0 || T <= 0) return false;
     const int R = T * (Hq / Hkv);
-    const int forced = env_int("NVLLM_PAGED_MAX_ROWS", 0);
+    const int forced = launch_policy().paged_max_rows;
     if (forced > 0) return R <= (forced < kMaxFastRows ? forced : kMaxFastRows);
     if (R <= 16) return true;
     if (R > kMaxFastRows) return false;
@@ -607,10 +601,10 @@ bool paged_attn_fast_path(DType dt, int num_seqs, int T, int Hq, int Hkv, int D,
 }
 
 int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq) {
-    const int forced = env_int("NVLLM_PAGED_SPLITS", 0);
+    const int forced = launch_policy().paged_splits;
     // aim for >= kWaveTarget (sequence, kv head, split) waves: 8 per CU on 256 CUs is one
     // resident 8-wave workgroup per CU, which measured best (config 3 then needs no merge pass)
-    const long kWaveTarget = env_int("NVLLM_PAGED_WAVE_TARGET", 2048);
+    const long kWaveTarget = launch_policy().paged_wave_target;
     const long waves = (long)num_seqs * num_kv_heads;
     // at least 16 blocks (256 tokens) per split; a launch that would stay under a quarter of the
     // wave target even then (a handful of sequences: latency, not throughput) goes down to 4 blocks
@@ -618,7 +612,7 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
     if (waves * (max_blocks_per_seq / 16 > 0 ? max_blocks_per_seq / 16 : 1) < kWaveTarget / 4) min_blocks = 4;
     int max_splits = max_blocks_per_seq / min_blocks;
     if (max_splits < 1) max_splits = 1;
-    if (max_splits > 64) max_splits = 64;  // the merge pass walks a row's splits one after the other
+    if (max_splits > 64) max_splits = 64;  // the merge kernel holds one split's (m, l) per lane
     if (forced > 0) return forced < max_splits ? forced : max_splits;
     long splits = (kWaveTarget + waves - 1) / (waves > 0 ? waves : 1);
     if (splits < 1) splits = 1;
@@ -652,9 +646,13 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
     if (a.num_seqs <= 0) return hipSuccess;
     if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                              a.block_size, a.max_blocks_per_seq)) {
-        int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);
+        const int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);
         const size_t rows = (size_t)a.num_seqs * a.num_new_tokens * a.num_heads;
-        if (splits > 1 && a.workspace_bytes < rows * splits * (kD + 2) * sizeof(float)) splits = 1;
+        // the C ABI has checked the workspace against paged_attn_workspace_bytes (same policy, same
+        // arithmetic); a direct caller that did not gets an error, never a silently different launch
+        if (splits > 1 && (!a.workspace || a.workspace_bytes < rows * splits * (kD + 2) * sizeof(float) ||
+                           (reinterpret_cast<uintptr_t>(a.workspace) & 15u) != 0))
+            return hipErrorInvalidValue;
         int bps = (a.max_blocks_per_seq + splits - 1) / splits;
         bps = (bps + kTileBlocks - 1) / kTileBlocks * kTileBlocks;
         if (bps < kTileBlocks) bps = kTileBlocks;
@@ -663,21 +661,15 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         // adaptive non-temporal K/V loads, unless the K/V the tables can reach fits the 256 MiB
         // Infinity Cache anyway (then a later layer / step may still find it there)
         const int64_t reach = (int64_t)a.num_seqs * a.max_blocks_per_seq * 2 * kBS * a.num_kv_heads * kRowBytes;
-        const bool nt = env_int("NVLLM_PAGED_NT", reach > ((int64_t)256 << 20) ? 1 : 0) != 0;
+        const int nt_forced = launch_policy().paged_nt;
+        const bool nt = nt_forced >= 0 ? nt_forced != 0 : reach > ((int64_t)256 << 20);
         const int R = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
         // kv heads per workgroup: 8 waves sharing a block's rows is the throughput shape; a launch
         // of fewer workgroups than CUs spreads its heads over more of them instead
-        int hpb = env_int("NVLLM_PAGED_HPB", 0);
+        int hpb = launch_policy().paged_hpb;
         if (hpb != 1 && hpb != 2 && hpb != 4 && hpb != 8) {
             hpb = a.num_kv_heads >= 8 ? 8 : (a.num_kv_heads >= 4 ? 4 : (a.num_kv_heads >= 2 ? 2 : 1));
-            static int num_cus = 0;
-            if (num_cus == 0) {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-                    n = 256;
-                num_cus = n;
-            }
+            const int num_cus = device_cus();
             while (hpb > 1 && (long)splits * a.num_seqs * ((a.num_kv_heads + hpb - 1) / hpb) < num_cus) hpb /= 2;
         }
         // two or more query tiles need the 512-register budget of a 4-wave workgroup (with 8 waves
@@ -705,7 +697,7 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
     }
     // more query rows per kv head (chunked prefill, long verify): the prefill kernel
     // reading K/V through the block table
-    if (env_int("NVLLM_PAGED_FLASH", 1) != 0 && flash_attn_paged_supported(dt, a))
+    if (launch_policy().paged_flash != 0 && flash_attn_paged_supported(dt, a))
         return launch_flash_attn_paged(a, stream);
     // generic
     const dim3 grid(a.num_heads, a.num_new_tokens, a.num_seqs), block(64);

@@ -63,8 +63,10 @@ template <bool NT> __device__ __forceinline__ void st16(__bf16 *p, u32x4 x) {
 
 template <bool NT>
 __global__ __launch_bounds__(256) void qk_norm_rope_cache_d128_kernel(
-    const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
-    __bf16 *__restrict__ q_out, __bf16 *__restrict__ k_out, const __bf16 *__restrict__ q_weight,
+    // q / q_out may be the same buffer (in-place is the default use), and k / k_out too: no
+    // __restrict__ on them; every row is read completely before anything of it is written
+    const __bf16 *q, const __bf16 *k, const __bf16 *__restrict__ v,
+    __bf16 *q_out, __bf16 *k_out, const __bf16 *__restrict__ q_weight,
     const __bf16 *__restrict__ k_weight, float eps, const __bf16 *__restrict__ cos_cache,
     const __bf16 *__restrict__ sin_cache, int max_pos, const int32_t *__restrict__ positions,
     __bf16 *__restrict__ k_cache, __bf16 *__restrict__ v_cache,
@@ -163,8 +165,8 @@ template <typename ET> __device__ __forceinline__ void st(ET *p, float x) { *p =
 
 template <typename ET>
 __global__ __launch_bounds__(256) void qk_norm_rope_cache_generic_kernel(
-    const ET *__restrict__ q, const ET *__restrict__ k, const ET *__restrict__ v,
-    ET *__restrict__ q_out, ET *__restrict__ k_out, const ET *__restrict__ q_weight,
+    const ET *q, const ET *k, const ET *__restrict__ v,  // q / q_out and k / k_out may alias
+    ET *q_out, ET *k_out, const ET *__restrict__ q_weight,
     const ET *__restrict__ k_weight, float eps, const ET *__restrict__ cos_cache,
     const ET *__restrict__ sin_cache, int max_pos, const int32_t *__restrict__ positions,
     ET *__restrict__ k_cache, ET *__restrict__ v_cache, const int64_t *__restrict__ slot_mapping,

@@ -74,7 +74,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void reshape_and_cache_small_k
     }
 }
 
+// LayerKVCache::gather_keys / gather_values (reference src/core/kv_cache.rs:123-144, an
+// index_select over dim 0): out[i] = cache[ids[i]], whole blocks.  The attention kernels never need
+// this copy (they read through the block table); it exists for callers that want the reference's
+// contiguous view, e.g. to hand a sequence's K/V to another engine.  Flat 16-byte mapping like the
+// scatter above; an id outside the pool yields a zero block.
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const u32x4 *__restrict__ cache,
+                                                            const int32_t *__restrict__ ids,
+                                                            u32x4 *__restrict__ out, int64_t total_vec,
+                                                            int block_vec, int64_t num_cache_blocks) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_vec) return;
+    const int64_t i = total_vec <= 0xffffffffLL ? (int64_t)((unsigned)gid / (unsigned)block_vec)
+                                                : gid / block_vec;
+    const int idx = (int)(gid - i * block_vec);
+    const int64_t id = ids[i];
+    u32x4 x = {0u, 0u, 0u, 0u};
+    if (id >= 0 && id < num_cache_blocks) x = cache[id * block_vec + idx];
+    __builtin_nontemporal_store(x, out + gid);
+}
+
 }  // namespace
+
+hipError_t launch_gather_blocks(const void *cache, const int32_t *ids, void *out, int64_t num_ids,
+                                int64_t block_bytes, int64_t num_cache_blocks, hipStream_t stream) {
+    if (num_ids <= 0) return hipSuccess;
+    if (block_bytes % 16 != 0 || block_bytes / 16 > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int block_vec = static_cast<int>(block_bytes / 16);
+    const int64_t total = num_ids * block_vec;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    gather_blocks_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream>>>(
+        static_cast<const u32x4 *>(cache), ids, static_cast<u32x4 *>(out), total, block_vec,
+        num_cache_blocks);
+    return hipGetLastError();
+}
 
 hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_cache,
                                     void *v_cache, const int64_t *slot_mapping,

@@ -54,6 +54,14 @@ def shard_cache_heads(cache, world, rank):
     return cache[:, :, b:e, :].contiguous()
 
 
+def assemble_heads(gathered, world):
+    """Rank-major concatenation [world * N, T, (Hq/n)*D] (what the all-gather delivers) ->
+    [N, T, Hq*D]: rank r's heads land at columns [r*(Hq/n)*D, (r+1)*(Hq/n)*D)."""
+    WN, T, HD = gathered.shape
+    N = WN // world
+    return gathered.view(world, N, T, HD).permute(1, 2, 0, 3).reshape(N, T, world * HD)
+
+
 def all_gather_heads(out_local, head_dim, group=None):
     """out_local [N, T, (Hq/n)*D] on every rank -> [N, T, Hq*D] on every rank.
     One all_gather_into_tensor (RCCL ncclAllGather) + a local permute of the small result."""
@@ -64,7 +72,7 @@ def all_gather_heads(out_local, head_dim, group=None):
     # output is the rank-major concatenation along dim 0 (the form every backend accepts)
     gathered = torch.empty((world * N, T, HD), dtype=out_local.dtype, device=out_local.device)
     dist.all_gather_into_tensor(gathered, out_local.contiguous(), group=group)
-    return gathered.view(world, N, T, HD).permute(1, 2, 0, 3).reshape(N, T, world * HD)
+    return assemble_heads(gathered, world)
 
 
 def gather_sequences(out_local, num_seqs, group=None):

@@ -29,3 +29,22 @@ def _built():
     if not os.path.exists(lib):
         import __graft_entry__
         __graft_entry__.build()
+
+
+class _Policy:
+    """Pins launch decisions through nvllm_debug_set_policy (the library reads the NVLLM_*
+    environment only once, so a test cannot steer it with setenv); everything is restored to the
+    environment's values when the test ends."""
+
+    def setenv(self, name, value):
+        import nano_vllm_rs_amd as nv
+        v = {"a": 1, "b": 0}.get(value, value) if isinstance(value, str) else value
+        rc = nv.capi.lib().nvllm_debug_set_policy(name.encode(), int(v))
+        assert rc == 0, nv.capi.last_error()
+
+
+@pytest.fixture
+def policy():
+    import nano_vllm_rs_amd as nv
+    yield _Policy()
+    nv.capi.lib().nvllm_debug_reset_policy()

@@ -67,3 +67,37 @@ def test_host_argument_validation_without_gpu():
                                      None, 0, None)
     assert rc == nv.capi.NVLLM_ERR_CONFIG
     assert "BlockTable is empty" in nv.capi.last_error()                             # paged.rs:135
+
+
+def test_workspace_and_launch_agree_or_the_call_fails(policy):
+    """nvllm_paged_attn_workspace_bytes and the launch take the split decision from the same policy
+    and arithmetic; a workspace smaller than that (or none) is NVLLM_ERR_CONFIG, never a silently
+    different launch.  Validation only: the fake pointers are never dereferenced."""
+    L = nv.capi.lib()
+    fake = ctypes.c_void_p(0x1000)
+    shape = (16, 1, 32, 8, 128, 16, 128)      # 16 sequences: split-K, workspace needed
+    need = L.nvllm_paged_attn_workspace_bytes(*shape)
+    assert need > 0
+    args = lambda ws, nbytes: (fake, fake, fake, fake, fake, fake, ws, nbytes, 16, 1, 32, 8, 128, 16,
+                               128, 4096, 0.1, None)
+    assert L.nvllm_paged_attn_bf16(*args(None, 0)) == nv.capi.NVLLM_ERR_CONFIG
+    assert "needs %d" % need in nv.capi.last_error()
+    assert L.nvllm_paged_attn_bf16(*args(fake, need - 1)) == nv.capi.NVLLM_ERR_CONFIG
+    assert L.nvllm_paged_attn_bf16(*args(ctypes.c_void_p(0x1008), need)) == nv.capi.NVLLM_ERR_CONFIG
+    assert "16-byte aligned" in nv.capi.last_error()
+    # the policy hook moves both sides together
+    policy.setenv("NVLLM_PAGED_SPLITS", 1)
+    assert L.nvllm_paged_attn_workspace_bytes(*shape) == 0
+    policy.setenv("NVLLM_PAGED_SPLITS", 4)
+    assert L.nvllm_paged_attn_workspace_bytes(*shape) == 16 * 32 * 4 * (128 + 2) * 4
+    assert L.nvllm_debug_set_policy(b"NVLLM_NO_SUCH_KNOB", 1) == nv.capi.NVLLM_ERR_CONFIG
+    L.nvllm_debug_reset_policy()
+    assert L.nvllm_paged_attn_workspace_bytes(*shape) == need
+
+
+def test_no_launch_path_reads_the_environment():
+    """The NVLLM_* overrides are read once (launch_policy.cpp); no kernel source calls getenv."""
+    csrc = os.path.join(ROOT, "nano-vllm-rs_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".hpp")) and f != "launch_policy.cpp":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f

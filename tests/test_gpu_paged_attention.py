@@ -128,11 +128,11 @@ def test_fast_path_multi_token_causal(dev, T):
 
 
 @pytest.mark.parametrize("pin", ["48", None])
-def test_fast_path_32_query_rows(dev, monkeypatch, pin):
+def test_fast_path_32_query_rows(dev, policy, pin):
     # T=8 with G=4 -> two 16-row query tiles in the decode kernel (pinned: a launch this small
     # would otherwise go to the prefill kernel over the cache, the second case)
     if pin:
-        monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", pin)
+        policy.setenv("NVLLM_PAGED_MAX_ROWS", pin)
     Hq, Hkv, D, bs, T = 32, 8, 128, 16, 8
     rng = np.random.default_rng(808)
     ctx_lens = [8, 40, 130, 515]
@@ -145,14 +145,14 @@ def test_fast_path_32_query_rows(dev, monkeypatch, pin):
 
 
 @pytest.mark.parametrize("T,splits", [(9, 0), (10, 2), (12, 0), (12, 3), (13, 0), (16, 0), (24, 0), (30, 0), (47, 0)])
-def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, monkeypatch):
+def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, policy):
     """More than 32 query rows per kv head: the decode kernel's third query tile (T = 9..12 at
     G = 4; with and without split-K; NVLLM_PAGED_MAX_ROWS pins the decode kernel, which the
     launcher would only pick for an HBM-bound launch), then the prefill kernel over the cache with
     the head group packed into its rows (T >= 13)."""
-    monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", "48")
+    policy.setenv("NVLLM_PAGED_MAX_ROWS", "48")
     if splits:
-        monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
+        policy.setenv("NVLLM_PAGED_SPLITS", str(splits))
     Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(900 + T)
     ctx_lens = [max(T, c) for c in (T, T + 3, T + 1, 16, 47, 48, 49, 130, 300, 515, 1000)]
@@ -165,8 +165,8 @@ def test_verify_lengths_around_the_kernel_boundary(dev, T, splits, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [12, 30])
-def test_context_shorter_than_the_new_tokens(dev, monkeypatch, T):
-    monkeypatch.setenv("NVLLM_PAGED_MAX_ROWS", "48")
+def test_context_shorter_than_the_new_tokens(dev, policy, T):
+    policy.setenv("NVLLM_PAGED_MAX_ROWS", "48")
     """Invalid for the reference (ctx >= T there); every kernel gives rows whose position is
     negative a zero output (T = 12: decode kernel, T = 30: packed prefill kernel; against the
     generic kernel)."""
@@ -188,9 +188,9 @@ def test_context_shorter_than_the_new_tokens(dev, monkeypatch, T):
 
 
 @pytest.mark.parametrize("splits", [1, 2, 3, 8])
-def test_split_k_matches_oracle(dev, splits, monkeypatch):
+def test_split_k_matches_oracle(dev, splits, policy):
     # K2b: forced split counts, contexts that leave some splits empty
-    monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
+    policy.setenv("NVLLM_PAGED_SPLITS", str(splits))
     Hq, Hkv, D, bs, T = 32, 8, 128, 16, 1
     rng = np.random.default_rng(splits)
     ctx_lens = [3, 200, 1024, 2048, 1555]
@@ -220,13 +220,13 @@ def test_shared_prefix_blocks_and_spec_verify(dev):
 
 @pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("prefix_blocks,splits", [(0, 1), (1, 1), (5, 1), (8, 2), (11, 3), (40, 1)])
-def test_adaptive_cache_policy_is_invisible(dev, monkeypatch, nt, prefix_blocks, splits):
+def test_adaptive_cache_policy_is_invisible(dev, policy, nt, prefix_blocks, splits):
     # K2 reads a shared leading prefix with the default cache policy and everything after it
     # non-temporally, in two separate tile loops; the switch-over tile (odd prefix lengths fall
     # in the middle of a 2-block tile), split boundaries and an odd sequence count (the last
     # sequence has no neighbour) must all give the oracle's result, with the policy on or off
-    monkeypatch.setenv("NVLLM_PAGED_NT", str(nt))
-    monkeypatch.setenv("NVLLM_PAGED_SPLITS", str(splits))
+    policy.setenv("NVLLM_PAGED_NT", str(nt))
+    policy.setenv("NVLLM_PAGED_SPLITS", str(splits))
     Hq, Hkv, D, bs, T = 32, 8, 128, 16, 1
     rng = np.random.default_rng(100 + prefix_blocks)
     ctx_lens = [700, 650, 1000, 777, 16 * prefix_blocks + 5 if prefix_blocks else 40, 900, 333]

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("seed,ksplit", [(11, None), (12, None), (13, "3")])
-def test_random_shapes_match_the_generic_kernel(dev, monkeypatch, seed, ksplit):
+def test_random_shapes_match_the_generic_kernel(dev, policy, seed, ksplit):
     if ksplit:
-        monkeypatch.setenv("NVLLM_K1_KSPLIT", ksplit)
+        policy.setenv("NVLLM_K1_KSPLIT", ksplit)
     rng = np.random.default_rng(seed)
     D, bs = 128, 16
     for case in range(30):

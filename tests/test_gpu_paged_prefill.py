@@ -91,7 +91,7 @@ def test_shared_prefix_blocks(dev):
     assert_attention_close(got, want)
 
 
-def test_context_shorter_than_chunk_matches_generic_kernel(dev, monkeypatch):
+def test_context_shorter_than_chunk_matches_generic_kernel(dev, policy):
     # invalid for the reference (a chunk's own K/V are in the cache, so ctx >= T); both kernels
     # give rows whose position is negative a zero output
     Hq, Hkv, D, bs, T = 32, 8, 128, 16, 50
@@ -102,7 +102,7 @@ def test_context_shorter_than_chunk_matches_generic_kernel(dev, monkeypatch):
     q = bf16_randn(rng, (4, T, Hq, D))
     scale = 1.0 / math.sqrt(D)
     got = _run(dev, q, kc, vc, tables, ctx_lens, scale)
-    monkeypatch.setenv("NVLLM_PAGED_FLASH", "0")
+    policy.setenv("NVLLM_PAGED_FLASH", "0")
     want = _run(dev, q, kc, vc, tables, ctx_lens, scale)
     assert (got[0] == 0).all()
     for i, ctx in enumerate(ctx_lens):
@@ -126,7 +126,7 @@ def test_large_scores_stay_finite(dev):
 
 @pytest.mark.parametrize("pack", [None, "0"])
 @pytest.mark.parametrize("S,T", [(4096, 4096), (4096, 512), (3000, 1000), (8192, 2048)])
-def test_paged_chunk_equals_contiguous_prefill(dev, monkeypatch, S, T, pack):
+def test_paged_chunk_equals_contiguous_prefill(dev, policy, S, T, pack):
     """Size-independent property at sizes the oracle would take minutes on: K/V written through
     reshape_and_cache and read back through the block table give the last T rows of the
     contiguous causal prefill over the same K/V (the K1 dense path, itself pinned to the oracle
@@ -135,7 +135,7 @@ def test_paged_chunk_equals_contiguous_prefill(dev, monkeypatch, S, T, pack):
     bit-identical.  Packed (the default) a wave holds other rows, so its deferred-rescale decisions
     may differ: same bar as everywhere else."""
     if pack is not None:
-        monkeypatch.setenv("NVLLM_K1_PACK", pack)
+        policy.setenv("NVLLM_K1_PACK", pack)
     Hq, Hkv, D, bs = 32, 8, 128, 16
     g = torch.Generator(device="cpu").manual_seed(S + T)
     k = torch.randn((1, S, Hkv, D), generator=g).to(dev, torch.bfloat16)
@@ -164,10 +164,10 @@ def test_paged_chunk_equals_contiguous_prefill(dev, monkeypatch, S, T, pack):
 # ---- key split of small launches (KSPLIT parts + merge kernel) -------------------------------
 @pytest.mark.parametrize("parts", [2, 3, 4, 8])
 @pytest.mark.parametrize("T", [40, 130, 300])
-def test_key_split_matches_oracle(dev, monkeypatch, parts, T):
+def test_key_split_matches_oracle(dev, policy, parts, T):
     # forced part counts, contexts short enough that some parts are empty, alignments that put
     # dead rows in front, both tile pairings
-    monkeypatch.setenv("NVLLM_K1_KSPLIT", str(parts))
+    policy.setenv("NVLLM_K1_KSPLIT", str(parts))
     Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(900 + parts * 10 + T)
     ctx_lens = [T, T + 1, T + 47, T + 64, T + 333, T + 1000]
@@ -177,12 +177,12 @@ def test_key_split_matches_oracle(dev, monkeypatch, parts, T):
     got = _run(dev, q, kc, vc, tables, ctx_lens, scale, fill=-1)
     want = oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, scale)
     assert_attention_close(got, want)
-    monkeypatch.setenv("NVLLM_K1_PAIRING", "a")
+    policy.setenv("NVLLM_K1_PAIRING", "a")
     got = _run(dev, q, kc, vc, tables, ctx_lens, scale, fill=-1)
     assert_attention_close(got, want)
 
 
-def test_key_split_is_chosen_for_one_long_chunk_and_matches_the_plain_launch(dev, monkeypatch):
+def test_key_split_is_chosen_for_one_long_chunk_and_matches_the_plain_launch(dev, policy):
     # one 512-token chunk against 4096 cached keys: 64 workgroups unsplit -> 4 parts by default
     Hq, Hkv, D, bs, T, S = 32, 8, 128, 16, 512, 4096
     L = nv.capi.lib()
@@ -198,7 +198,7 @@ def test_key_split_is_chosen_for_one_long_chunk_and_matches_the_plain_launch(dev
     cl = torch.tensor([S - 5], dtype=torch.int32, device=dev)
     scale = 1 / math.sqrt(D)
     split = nv.paged_attention_batched(q, kc, vc, bt, cl, scale).float()
-    monkeypatch.setenv("NVLLM_K1_KSPLIT", "1")
+    policy.setenv("NVLLM_K1_KSPLIT", "1")
     plain = nv.paged_attention_batched(q, kc, vc, bt, cl, scale).float()
     torch.cuda.synchronize()
     d = (split - plain).abs()
