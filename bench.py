@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|verify|prefill|kvwrite|producer]
 
+`python bench.py --gpus N` with N > 1 starts N fresh rank processes itself (through
+torch.distributed.run on 127.0.0.1; the parent touches no GPU API); started under
+torch.distributed.run by someone else (WORLD_SIZE set) it is one of the ranks.
+
 Headline (default, BASELINE.json `metric`): paged-decode attention GB/s on
 BASELINE config 3 -- 256 sequences x 2048-token contexts, 32 Q / 8 KV heads,
 head_dim 128, block_size 16, bf16, physical blocks a seeded random permutation
@@ -41,7 +45,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md, spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec; not the 2:1-sparse figure)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -56,20 +60,84 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--launcher-check", action="store_true",
+                    help="CPU-only rehearsal of the N-rank launch path (gloo, no GPU work): rank 0 "
+                         "prints {launcher_check, world, ranks_seen}")
+    ap.add_argument("--launcher-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(args, argv, port):
+    """What `python bench.py --gpus N` (N > 1, not yet under a launcher) starts: N fresh
+    processes, one rank per GPU, through torch.distributed.run -- the same command line the
+    driver uses."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_children(args, argv):
+    """Parent of an N > 1 run started as plain `python bench.py --gpus N`.  Touches no GPU API
+    (a process that has initialised HIP must not be the one that spawns the ranks); the ranks are
+    fresh child processes, rank 0's JSON line passes through on stdout, and the exit code is
+    non-zero if any rank failed."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(launcher_command(args, argv, free_port()), env=env)
+    return proc.returncode
+
+
+def launcher_check(args):
+    """One rank of --launcher-check: rendezvous over gloo on the CPU, confirm the world size,
+    count the ranks with one all-reduce.  No GPU API is touched."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world > 1:
+        dist.init_process_group("gloo")
+    if rank == args.launcher_check_fail_rank:
+        raise SystemExit(3)
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(launcher_check=True, world=world, ranks_seen=int(seen.item()),
+                              workload=args.workload)))
+    return 0
 
 
 def dist_setup(n):
+    """Rank set-up of a worker.  Returns (rank, local_rank, world, rccl_ranks_seen): the last is
+    the sum of a one per rank over an RCCL all-reduce (None at N = 1: no collective exists)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if n > 1 and world != n:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (n, world))
+    if world != n:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, n))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    seen = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    return rank, local_rank, world
+        t = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t)
+        seen = int(t.item())
+    return rank, local_rank, world, seen
 
 
 def barrier(world):
@@ -379,11 +447,15 @@ def pmc_traffic(key):
         return None
 
 
-def main():
-    args = parse()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    rank, local_rank, world = dist_setup(args.gpus)
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher; no GPU API before this point
+        return launch_children(args, argv)
+    if args.launcher_check:
+        return launcher_check(args)
+    rank, local_rank, world, rccl_seen = dist_setup(args.gpus)
     dev = torch.device("cuda", local_rank)
     import nano_vllm_rs_amd as nv
     nv.capi.lib()
@@ -436,12 +508,15 @@ def main():
     )
     if also:
         line["also"] = also
+    if world > 1:
+        line["rccl_ranks_seen"] = rccl_seen
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
