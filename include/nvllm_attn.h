@@ -119,6 +119,23 @@ int nvllm_paged_attn_f32(const void *q, const void *k_cache, const void *v_cache
                          int max_blocks_per_seq, int64_t num_cache_blocks, float scale,
                          nvllm_stream_t stream);
 
+/* nvllm_paged_attn_bf16 for callers that CANNOT allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same kernels and bit-identical results, minus the workspace: the
+ * split-K partials go to a scratch array built into the library's code object
+ * (nvllm_paged_attn_noalloc_max_scratch_bytes() = 32 MiB, held by every GPU the library runs on
+ * until the process ends).  A launch shape whose nvllm_paged_attn_workspace_bytes() exceeds that
+ * is refused with NVLLM_ERR_UNSUPPORTED (nothing is launched); shapes that need no workspace
+ * never touch the scratch.  The call allocates and frees nothing and does not synchronise.  All
+ * calls on one GPU share that GPU's array: two calls that overlap in time on one GPU (different
+ * streams, or threads) race on it -- serialise them or use the workspace form. */
+int nvllm_paged_attn_bf16_noalloc(const void *q, const void *k_cache, const void *v_cache,
+                                  const int32_t *block_tables, const int32_t *context_lens, void *out,
+                                  int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
+                                  int head_dim, int block_size, int max_blocks_per_seq,
+                                  int64_t num_cache_blocks, float scale, nvllm_stream_t stream);
+size_t nvllm_paged_attn_noalloc_max_scratch_bytes(void);
+
 /* Bytes of split-K scratch nvllm_paged_attn_* needs for this launch shape
  * (an upper bound over all context lengths <= max_blocks_per_seq*block_size).
  * The launch takes its split decision from the same arguments by the same

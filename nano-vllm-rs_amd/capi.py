@@ -30,6 +30,8 @@ SIGNATURES = {
     "nvllm_flash_attn_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "nvllm_paged_attn_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i64, _f, _vp]),
     "nvllm_paged_attn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i64, _f, _vp]),
+    "nvllm_paged_attn_bf16_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _f, _vp]),
+    "nvllm_paged_attn_noalloc_max_scratch_bytes": (_sz, []),
     "nvllm_paged_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "nvllm_reshape_and_cache_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),
     "nvllm_reshape_and_cache_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),

@@ -77,7 +77,7 @@ int paged_common(kernels::DType dt, const void *q, const void *k_cache, const vo
                  void *workspace, size_t workspace_bytes, int num_seqs, int num_new_tokens,
                  int num_heads, int num_kv_heads, int head_dim, int block_size,
                  int max_blocks_per_seq, int64_t num_cache_blocks, float scale,
-                 nvllm_stream_t stream) {
+                 nvllm_stream_t stream, bool noalloc = false) {
     if (!q || !k_cache || !v_cache || !block_tables || !context_lens || !out)
         return fail(ErrorKind::Null, "paged_attn: null pointer");
     if (num_seqs < 0 || num_new_tokens <= 0 || num_heads <= 0 || num_kv_heads <= 0 ||
@@ -106,6 +106,16 @@ int paged_common(kernels::DType dt, const void *q, const void *k_cache, const vo
                                                                   num_kv_heads, head_dim, block_size,
                                                                   max_blocks_per_seq)
                             : 0;
+    if (noalloc) {
+        if (need > kernels::kNoAllocScratchBytes)
+            return fail(ErrorKind::Unsupported,
+                        "paged_attn_noalloc: this launch shape needs " + std::to_string(need) +
+                            " bytes of split-K scratch, the built-in scratch holds " +
+                            std::to_string(kernels::kNoAllocScratchBytes) +
+                            "; use nvllm_paged_attn_bf16 with a caller workspace");
+        return hip_status(kernels::launch_paged_attn_noalloc(dt, a, as_stream(stream)),
+                          "paged_attn_noalloc launch");
+    }
     if (need > 0 && (!workspace || workspace_bytes < need))
         return fail(ErrorKind::Config, "paged_attn: workspace of " + std::to_string(workspace ? workspace_bytes : 0) +
                                            " bytes, this launch shape needs " + std::to_string(need) +
@@ -190,6 +200,18 @@ int nvllm_paged_attn_bf16(const void *q, const void *k_cache, const void *v_cach
                         num_kv_heads, head_dim, block_size, max_blocks_per_seq, num_cache_blocks,
                         scale, stream);
 }
+
+int nvllm_paged_attn_bf16_noalloc(const void *q, const void *k_cache, const void *v_cache,
+                                  const int32_t *block_tables, const int32_t *context_lens, void *out,
+                                  int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
+                                  int head_dim, int block_size, int max_blocks_per_seq,
+                                  int64_t num_cache_blocks, float scale, nvllm_stream_t stream) {
+    return paged_common(kernels::DType::BF16, q, k_cache, v_cache, block_tables, context_lens, out,
+                        nullptr, 0, num_seqs, num_new_tokens, num_heads, num_kv_heads, head_dim,
+                        block_size, max_blocks_per_seq, num_cache_blocks, scale, stream, true);
+}
+
+size_t nvllm_paged_attn_noalloc_max_scratch_bytes(void) { return kernels::kNoAllocScratchBytes; }
 
 int nvllm_paged_attn_f32(const void *q, const void *k_cache, const void *v_cache,
                          const int32_t *block_tables, const int32_t *context_lens, void *out,

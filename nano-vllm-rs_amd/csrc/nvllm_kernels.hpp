@@ -99,6 +99,10 @@ size_t paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_head
                                   int num_kv_heads, int head_dim, int block_size,
                                   int max_blocks_per_seq);
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream);
+// the same launch with the split-K scratch in a file-scope device array of paged_attn.hip
+// (a.workspace is ignored); launches that need more than kNoAllocScratchBytes are refused
+constexpr size_t kNoAllocScratchBytes = (size_t)32 << 20;
+hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &a, hipStream_t stream);
 // K1 over the paged cache (flash_attn_mfma.hip): chunked prefill / verify with more than 32 query
 // rows per kv head; launch_paged_attn dispatches to it
 bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a);

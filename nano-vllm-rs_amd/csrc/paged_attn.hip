@@ -62,6 +62,7 @@
 
 #include <type_traits>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -640,6 +641,55 @@ size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, i
     if (splits <= 1) return 0;
     const size_t rows = (size_t)num_seqs * T * Hq * splits;
     return rows * (kD + 2) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (nvllm_paged_attn_bf16_noalloc): the split-K
+// partials live in this file-scope device array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy (kNoAllocScratchBytes, until the process ends) at its own
+// address, so host code never uses the array's name as an address: the address is asked for once
+// per device with hipGetSymbolAddress and only that pointer is handed to the kernels.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+namespace {
+// device address of `scratch` on the CURRENT device (looked up on the first call per device)
+hipError_t noalloc_scratch(void **out) {
+    constexpr int kMaxDevices = 64;
+    static std::atomic<void *> ptrs[kMaxDevices];
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    void *p = ptrs[dev].load(std::memory_order_acquire);
+    if (!p) {
+        err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (err != hipSuccess) return err;
+        if (!p) return hipErrorInvalidSymbol;
+        ptrs[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &args, hipStream_t stream) {
+    PagedAttnArgs a = args;
+    a.workspace = nullptr;
+    a.workspace_bytes = 0;
+    const size_t need = dt == DType::BF16
+                            ? paged_attn_workspace_bytes(a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads,
+                                                         a.head_dim, a.block_size, a.max_blocks_per_seq)
+                            : 0;
+    if (need > kNoAllocScratchBytes) return hipErrorOutOfMemory;  // the C ABI rejects this before
+    if (need > 0) {
+        void *p = nullptr;
+        const hipError_t err = noalloc_scratch(&p);
+        if (err != hipSuccess) return err;
+        a.workspace = p;  // every partial the merge pass reads is written by this launch first:
+        a.workspace_bytes = kNoAllocScratchBytes;  // nothing in it has to start at zero
+    }
+    return launch_paged_attn(dt, a, stream);
 }
 
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {
