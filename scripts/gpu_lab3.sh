@@ -1,0 +1,8 @@
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lab_r02c.txt; : > $O
+cd $R
+L=./scripts/k1_lab/k1_lab
+for args in "B=8 S=4096" "B=1 S=4096" "B=2 S=1024" "B=1 S=4096 spike=1"; do
+  timeout -k 10 100 $L $args rounds=3 >> $O 2>&1 || { echo "FAILED: $args" >> $O; tail -5 $O; exit 1; }
+done
+grep -E "shape|median|cycles per wave|stamps over|check" $O

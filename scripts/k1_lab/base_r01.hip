@@ -80,7 +80,7 @@ constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^
 // Diagnostic build only (scripts/k1_lab, -DNVLLM_K1_STAMPS): per-wave cycle sums of the loop's
 // segments, written through the lse pointer.  In the product build no stamp executes.
 #ifdef NVLLM_K1_STAMPS
-#define K1_STAMP_IMPL(i)                                                                   \
+#define K1_STAMP(i)                                                                        \
     do {                                                                                   \
         unsigned long long t_;                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -89,24 +89,8 @@ constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^
         seg_sum[i] += t_ - t_prev;                                                         \
         t_prev = t_;                                                                       \
     } while (0)
-#ifdef K1_FINE
-#define K1_STAMP(i)                                                                        \
-    do {                                                                                   \
-        if ((i) == 11 || (i) == 2) K1_STAMP_IMPL(i);                                        \
-        else K1_STAMP_IMPL(10);                                                            \
-    } while (0)
-#else
-#define K1_STAMP(i) K1_STAMP_IMPL(i)
-#endif
 #else
 #define K1_STAMP(i)
-#endif
-// finer diagnostic (-DNVLLM_K1_STAMPS -DK1_FINE): cycles per 8-slice group of the dual slots
-// (0..3 = QK^T groups, 4..8 = P.V groups) instead of the per-segment sums; 11 = barrier
-#if defined(NVLLM_K1_STAMPS) && defined(K1_FINE)
-#define K1_FSTAMP(i) K1_STAMP_IMPL(i)
-#else
-#define K1_FSTAMP(i)
 #endif
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -135,9 +119,12 @@ __device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32
 struct Item {
     f32x16 sa, sb;  // keys 0..31 / 32..63 of the tile
     u32x4 p[4];     // P^T B fragments, k-step 2u + sh
+    float mc;       // reference max * scale * log2(e)
+    float alpha;    // pending O rescale factor
     float mx;       // running max of the raw scores
     float xf;       // exponent of the element in flight (s*c - m*c)
     float ya, yb;   // exponentials of an even / odd element waiting to be packed
+    bool need;      // wave-uniform: alpha != 1
 };
 
 // Per-block softmax state.  The O^T accumulators and the Q^T fragments of both blocks live in the
@@ -149,9 +136,7 @@ struct Item {
 // compiler never spills (checked at build time: zero spills, no v_accvgpr outside the asm
 // statements), so nothing else ever lands in a[0:223].
 struct Block {
-    float m;    // reference max of the running softmax
-    float mc;   // m * scale * log2(e) (0 while m is -inf)
-    float thr;  // a row max above this makes the wave re-reference: m + kDeferLog2 / (scale * log2(e))
+    float m;   // reference max of the running softmax
 #ifdef K1_DBG_VALU_L
     float l;
 #endif
@@ -239,125 +224,6 @@ __device__ __forceinline__ void pin(float &x, float &y, u32x4 &z) {
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
 }
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
-
-// fmaxf on MFMA outputs makes hipcc canonicalise every input first (v_max_f32 x, x, x): the running
-// max is written as the single instructions it should be
-__device__ __forceinline__ float max2_asm(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float max3_asm(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// ---- how an item's softmax is dealt out over the MFMA gaps ------------------------------------
-// The vector-ALU work of one item (32 rows x 64 keys) is a fixed sequence of single instructions
-// ("units"): 16 x running max (two scores per v_max3), then the element pipeline tick by tick, which
-// starts SPECULATIVELY against the block's current reference max (the decision whether that
-// reference still holds is one compare and one branch at the very end of the P.V slot, see
-// decide_after_pv) -- tick n packs the pair that ended at element
-// n - 2 (odd n), exponentiates element n - 1 and multiplies element n, so that no instruction waits
-// for the one in front of it.  The units up to and including tick kFirstTicks - 1 run in the gaps of
-// the P.V slot that follows the item's QK^T, the rest in the gaps of the next QK^T slot.  One wave
-// per SIMD hides about 24 issue cycles per 32-cycle MFMA and nothing averages out between gaps (an
-// over-full gap idles the matrix pipe, an under-full one stalls the wave at its next MFMA), so the
-// units are dealt by COST: every gap of a slot gets the same total of vector-ALU issue cycles plus
-// the LDS / global instructions that gap issues anyway.  Costs are issue cycles measured on gfx950
-// (MI355X_MICROARCH.md: v_exp 8, v_fma / v_max3 4, v_cvt_pk 4.5, ds_read 4, ds_write_b128 13,
-// buffer_load ~8).
-enum UnitKind { kUMax = 0, kUPack = 2, kUExp = 3, kUFma = 4 };
-constexpr int kTicksTotal = 34, kFirstTicks = 17;  // ticks in all / beside the P.V slot
-constexpr int kMaxUnits = 16 + 80, kPvSlices = 20, kQkSlices = 16;
-struct UnitTab {
-    int kind[kMaxUnits], arg[kMaxUnits];
-    int count, split;  // split = first unit of the QK^T slot's share
-};
-constexpr UnitTab make_units() {
-    UnitTab t{};
-    int u = 0;
-    for (int j = 0; j < 16; ++j) { t.kind[u] = kUMax; t.arg[u++] = j; }
-    for (int n = 0; n < kTicksTotal; ++n) {
-        if (n == kFirstTicks) t.split = u;
-        if (n >= 3 && (n & 1)) { t.kind[u] = kUPack; t.arg[u++] = n - 2; }   // pair ending at element n - 2
-        if (n >= 1 && n <= 32) { t.kind[u] = kUExp; t.arg[u++] = n - 1; }    // element n - 1
-        if (n < 32) { t.kind[u] = kUFma; t.arg[u++] = n; }                   // element n
-    }
-    t.count = u;
-    return t;
-}
-constexpr UnitTab kUnitTab = make_units();
-static_assert(kUnitTab.count == kMaxUnits, "unit count");
-// issue cost beside an MFMA stream, one wave per SIMD, in tenths of a cycle (scripts/k1_lab/micro/
-// gap_cost.hip: the MFMA itself holds the issue port for ~8.5 of its 32 cycles, a plain VALU
-// instruction costs ~5.3, v_exp_f32 ~10, and -- whatever the sum -- a second v_exp_f32 in a gap
-// that already holds more than three fillers costs another ~8: {exp fma exp fma cvt} runs 42.5
-// cycles per MFMA, {exp fma cvt} and {exp fma} 34 and 33.5)
-constexpr int unit_cost(int u) { return kUnitTab.kind[u] == kUExp ? 100 : 53; }
-constexpr int kGapBudget = 235;  // tenths of a cycle of fillers per gap
-enum DealMode { kDealSingle = 0, kDealDualA = 1, kDealDualB = 2 };
-// memory instructions a slice issues besides its MFMA: fragment reads of the next group (~4.5
-// cycles each), staging writes (ds_write_b128 ~13) / loads (~8)
-constexpr int pv_mem_cost(int mode, int i) {
-    if (i >= 16) return 0;
-    if (mode == kDealSingle) return (i & 3) < 2 ? 180 : 80;            // 4 tr reads | one buffer load
-    return ((i & 3) < 2 ? 90 : 0) + ((mode == kDealDualB && (i & 1)) ? 80 : 0);
-}
-constexpr int qk_mem_cost(int mode, int i) {
-    const bool last_group = i >= 12;                                   // prefetch of the first V^T fragments
-    if (mode == kDealSingle) return (i & 3) < 2 ? (last_group ? 180 : 90) : 130;
-    return ((i & 3) < 2 ? (last_group ? 90 : 45) : 0) + ((mode == kDealDualB && (i & 1)) ? 130 : 0);
-}
-struct DealPlan {
-    int cum[kPvSlices + kQkSlices + 2];  // units finished before P.V slice i / before QK^T slice i - 20
-};
-constexpr DealPlan make_deal_plan(int mode) {
-    DealPlan p{};
-    // P.V slot: units [0, split) over its 20 slices; QK^T slot: the rest over its 16 slices.  A gap
-    // takes units in order while they fit its budget, at most one v_exp_f32 -- unless the exps still
-    // to come outnumber the gaps still to come, and then as late as possible.
-    for (int slot = 0; slot < 2; ++slot) {
-        const int n = slot == 0 ? kPvSlices : kQkSlices;
-        const int u0 = slot == 0 ? 0 : kUnitTab.split, u1 = slot == 0 ? kUnitTab.split : kUnitTab.count;
-        const int base = slot == 0 ? 0 : kPvSlices;
-        int exps_left = 0, work_left = 0;
-        for (int u = u0; u < u1; ++u) {
-            exps_left += kUnitTab.kind[u] == kUExp;
-            work_left += unit_cost(u);
-        }
-        int u = u0;
-        for (int i = 0; i < n; ++i) {
-            p.cum[base + i] = u;
-            const int mem = slot == 0 ? pv_mem_cost(mode, i) : qk_mem_cost(mode, i);
-            // budget of this gap: the common one, or this gap's fair share of what is left if that is more
-            int cap_left = 0;
-            for (int j = i; j < n; ++j) {
-                const int m = slot == 0 ? pv_mem_cost(mode, j) : qk_mem_cost(mode, j);
-                cap_left += kGapBudget > m ? kGapBudget - m : 0;
-            }
-            int budget = kGapBudget - mem;
-            if (work_left > cap_left) budget += (work_left - cap_left) / (n - i);
-            int spent = 0, exps = 0;
-            while (u < u1) {
-                const bool is_exp = kUnitTab.kind[u] == kUExp;
-                if (i < n - 1) {
-                    if (is_exp && exps >= 1 && exps_left <= n - 1 - i) break;
-                    if (spent + unit_cost(u) > budget && !(is_exp && exps == 0 && exps_left > n - 1 - i)) break;
-                }
-                spent += unit_cost(u);
-                work_left -= unit_cost(u);
-                exps += is_exp;
-                exps_left -= is_exp;
-                ++u;
-            }
-        }
-        if (slot == 0) p.cum[kPvSlices] = kUnitTab.split;
-    }
-    p.cum[kPvSlices + kQkSlices] = kUnitTab.count;
-    return p;
-}
 
 // PAGED = K/V come from the paged cache ([num_blocks, 16, Hkv, 128], k / v = cache bases) through
 // this sequence's block table, Skv is the sequence's context length and the causal mask is
@@ -507,8 +373,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         static_for<64>([&](auto R) { agpr_write<64 * bi + decltype(R)::value>(0u); });
         static_for<16>([&](auto R) { agpr_write<192 + 16 * bi + decltype(R)::value>(0u); });
         blk.m = -INFINITY;
-        blk.mc = 0.0f;
-        blk.thr = -INFINITY;
     };
     auto commit_q = [&](auto bt, const u32x4 (&x)[8]) {
         constexpr int bi = decltype(bt)::value;
@@ -637,122 +501,92 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef K1_DBG_VALU_L
     float dbg_l = 0.f;  // only valid for single-block (nB == 0) waves without rescale
 #endif
-    const float defer_raw = kDeferLog2 / scale_log2e;  // the rescale threshold in raw score units
     // ---- vector-ALU steps of one item's softmax, cut so that they can be dealt out between MFMAs
     // running max, step j of 16: sa pairs first (their MFMAs finished long ago), then sb pairs
-    // (two alternating chains -- it.mx on even steps, it.xf, idle until the first element, on odd
-    // ones -- so that no v_max3 reads the result of the instruction just before it; step 15 joins them)
     auto max_step = [&](Item &it, int j) {
         const int r = 2 * (j & 7);
-        float &acc = (j & 1) ? it.xf : it.mx;
-        if (j < 2) acc = max2_asm(it.sa[r], it.sa[r + 1]);
-        else if (j < 8) acc = max3_asm(acc, it.sa[r], it.sa[r + 1]);
-        else acc = max3_asm(acc, it.sb[r], it.sb[r + 1]);
-        if (j == 15) it.mx = max2_asm(it.mx, it.xf);
+        if (j == 0) it.mx = fmaxf(it.sa[0], it.sa[1]);
+        else if (j < 8) it.mx = fmaxf(fmaxf(it.mx, it.sa[r]), it.sa[r + 1]);
+        else it.mx = fmaxf(fmaxf(it.mx, it.sb[r]), it.sb[r + 1]);
+    };
+    // deferred-rescale decision (wave-uniform), new reference max; O and l are rescaled later
+    // (just before this item's P.V)
+    auto decide = [&](Item &it, Block &blk) {
+        const float mx = half_max(it.mx);
+        // keep the old reference max while every row max of the wave grew by less than
+        // kDeferLog2 (exp2 domain): P stays <= 2^kDeferLog2
+        const bool need = __any((mx - blk.m) * scale_log2e > kDeferLog2);
+        const float m_new = need ? fmaxf(blk.m, mx) : blk.m;
+        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = need ? fast_exp2((blk.m - m_safe) * scale_log2e) : 1.0f;
+        blk.m = m_new;
+        it.mc = m_safe * scale_log2e;
+        it.alpha = alpha;
+        it.need = need;
     };
     // The 32 elements of an item, p = exp2(s*c - m*c) packed to bf16 pairs (the row sum is an MFMA:
     // ones . P^T), as a 3-stage pipeline over 34 ticks so that no instruction waits for the one
     // just before it: tick n multiplies element n, exponentiates element n-1 and packs the pair
     // that ended at element n-2.
-    auto el_pack = [&](Item &it, int e) {  // e = odd element that closes a pair
-        it.p[e >> 3][(e & 7) >> 1] = pack_bf16x2(it.ya, it.yb);
+    auto tick = [&](Item &it, int n) {
+        if (n >= 3 && (n & 1)) {
+            const int e = n - 2;
+            it.p[e >> 3][(e & 7) >> 1] = pack_bf16x2(it.ya, it.yb);
+        }
+        if (n >= 1 && n <= 32) {
+            const float y = fast_exp2(it.xf);
+            if ((n - 1) & 1) it.yb = y;
+            else it.ya = y;
+        }
+        if (n < 32) {
+            const float sv = n < 16 ? it.sa[n & 15] : it.sb[n & 15];
+            it.xf = __builtin_fmaf(sv, scale_log2e, -it.mc);
+        }
     };
-    auto el_exp = [&](Item &it, int e) {
-        const float y = fast_exp2(it.xf);
-        if (e & 1) it.yb = y;
-        else it.ya = y;
-    };
-    auto el_fma = [&](Item &it, const Block &blk, int e) {
-        const float sv = e < 16 ? it.sa[e & 15] : it.sb[e & 15];
-        it.xf = __builtin_fmaf(sv, scale_log2e, -blk.mc);
-    };
-    auto tick = [&](Item &it, const Block &blk, int n) {
-        if (n >= 3 && (n & 1)) el_pack(it, n - 2);
-        if (n >= 1 && n <= 32) el_exp(it, n - 1);
-        if (n < 32) el_fma(it, blk, n);
-    };
-    constexpr int kTicks = kTicksTotal, kFirst = kFirstTicks;
+    constexpr int kTicks = 34, kFirst = 16;  // ticks in all / run beside the P.V slot
     auto deps_of = [&](const Item &it) {
-        return Deps{it.mx, it.mx, it.xf, it.ya, it.yb, it.p[0], it.p[1], it.p[2], it.p[3]};
+        return Deps{it.mx, it.mc, it.xf, it.ya, it.yb, it.p[0], it.p[1], it.p[2], it.p[3]};
     };
-    // Deferred rescale (T13).  The old reference max of a block is kept while every row max of the
-    // wave stays within kDeferLog2 (exp2 domain) of it: P <= 2^kDeferLog2.  That is the common case,
-    // so the element pipeline of a fresh item starts against the old reference before anyone has
-    // looked, and the check is ONE compare (each lane tests the max of its half of the row's keys
-    // against the row's threshold; the halves only meet when the branch is taken) and ONE branch per
-    // step for both blocks -- a branch costs this kernel 75-150 cycles (instruction fetch restarts
-    // with nothing to hide it at one wave per SIMD), so there is exactly one in a step.  It sits
-    // behind the last MFMA of the P.V slot: everything in O and l is then at the old reference and
-    // the only pending values are the item's own speculative elements, so the rare path rescales
-    // O and l on the spot (register by register through the vector ALU) and redoes those elements
-    // against the new reference -- every value still at the old max is scaled exactly once.
-    auto rereference = [&](Item &it, Block &blk, auto bt, int ticks_done) {
-        if (!__any(it.mx > blk.thr)) return;  // (inside the rare branch: which of the blocks it was)
-        constexpr int bi = decltype(bt)::value;
-        const float mx = half_max(it.mx);
-        const float m_new = fmaxf(blk.m, mx);
-        const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-        const float alpha = fast_exp2((blk.m - m_safe) * scale_log2e);
-        blk.m = m_new;
-        blk.mc = m_safe * scale_log2e;
-        blk.thr = m_new + defer_raw;
-        mfma_fence();
-        static_for<64>([&](auto R) { agpr_scale<64 * bi + decltype(R)::value>(alpha); });
-        static_for<16>([&](auto R) { agpr_scale<192 + 16 * bi + decltype(R)::value>(alpha); });
-        mfma_fence();
-#pragma unroll
-        for (int n = 0; n < kTicks; ++n)
-            if (n < ticks_done) tick(it, blk, n);
-    };
-#ifdef K1_ABL_NOBRANCH
-    int abl_sticky = 0;
-#endif
-    auto decide_after_pv = [&](Item &it, Block &blk, auto bt) {
-#ifdef K1_ABL_NOBRANCH  // lab only: the compare without the branch (wrong results, prices the branch)
-        abl_sticky |= __any(it.mx > blk.thr);
-        return;
-#endif
-        if (__builtin_expect(__any(it.mx > blk.thr), 0)) rereference(it, blk, bt, kFirst);
-    };
-    auto decide_after_pv2 = [&](Item &ia, Item &ib) {
-#ifdef K1_ABL_NOBRANCH
-        abl_sticky |= __any((ia.mx > A.thr) | (ib.mx > B.thr));
-        return;
-#endif
-        if (__builtin_expect(__any((ia.mx > A.thr) | (ib.mx > B.thr)), 0)) {
-            rereference(ia, A, kA, kFirst);
-            rereference(ib, B, kB, kFirst);
+    // O^T *= alpha, l *= alpha: rare (deferred), so done register by register through the vector ALU
+    auto rescale = [&](const Item &it, auto bt) {
+        if (it.need) {
+            constexpr int bi = decltype(bt)::value;
+            const float f = it.alpha;
+            mfma_fence();
+            static_for<64>([&](auto R) { agpr_scale<64 * bi + decltype(R)::value>(f); });
+            static_for<16>([&](auto R) { agpr_scale<192 + 16 * bi + decltype(R)::value>(f); });
+            mfma_fence();
         }
     };
     // VALU share of slice i (of 20) of a P.V slot: statistics of the item whose QK^T just
     // finished, then its first kFirst elements
-    // unit u of an item's softmax (kUnitTab)
-    auto unit = [&](Item &it, Block &blk, auto U) {
-        constexpr int u = decltype(U)::value, kind = kUnitTab.kind[u], arg = kUnitTab.arg[u];
-#ifdef K1_ABL_SKIP_KINDS  // lab only: drop unit kinds (bit mask) to price them; results are wrong
-        if constexpr ((K1_ABL_SKIP_KINDS >> kind) & 1) return;
-#endif
-        if constexpr (kind == kUMax) max_step(it, arg);
-        else if constexpr (kind == kUPack) el_pack(it, arg);
-        else if constexpr (kind == kUExp) el_exp(it, arg);
-        else el_fma(it, blk, arg);
-    };
-    // the units make_deal_plan(MODE) gives slice I of a P.V slot (of 20) / of a QK^T slot (of 16)
-    auto valu_pv = [&](Item &it, Block &blk, auto M, auto I) {
+    auto valu_pv = [&](Item &it, Block &blk, int i) {
 #ifdef K1_ABL_NOVALU
         return;
 #endif
-        constexpr DealPlan plan = make_deal_plan(decltype(M)::value);
-        constexpr int i = decltype(I)::value, u0 = plan.cum[i], u1 = plan.cum[i + 1];
-        static_for<u1 - u0>([&](auto J) { unit(it, blk, ic<u0 + decltype(J)::value>{}); });
+        if (i < 4) {
+#pragma unroll
+            for (int j = 4 * i; j < 4 * i + 4; ++j) max_step(it, j);
+        } else if (i == 4) {
+            decide(it, blk);
+        } else if (i == 5) {
+            tick(it, 0);
+            tick(it, 1);
+        } else {
+            tick(it, i - 4);  // 6..19 -> ticks 2..15
+        }
     };
-    auto valu_qk = [&](Item &it, Block &blk, auto M, auto I) {
+    // VALU share of slice i (of 16) of a QK^T slot: the remaining 17 elements of the other item
+    auto valu_qk = [&](Item &it, int i) {
 #ifdef K1_ABL_NOVALU
         return;
 #endif
-        constexpr DealPlan plan = make_deal_plan(decltype(M)::value);
-        constexpr int i = decltype(I)::value, u0 = plan.cum[kPvSlices + i], u1 = plan.cum[kPvSlices + i + 1];
-        static_for<u1 - u0>([&](auto J) { unit(it, blk, ic<u0 + decltype(J)::value>{}); });
+        if (i < 14) {
+            tick(it, kFirst + i);  // ticks 16..29
+        } else {
+            tick(it, 2 * i + 2);   // 14 -> 30, 31; 15 -> 32, 33
+            tick(it, 2 * i + 3);
+        }
     };
 
     // ---- pipelined slots.  Slice = { MFMA ; LDS reads ; a few VALU }.  Fragment group g + 1 is read
@@ -778,7 +612,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef K1_DBG_FENCE
             mfma_fence();
 #endif
-            valu(ic<i>{});
+            valu(i);
             // hipcc may copy the fresh scores right behind the last MFMA (it does not know the
             // statement is one): keep the MFMA -> VALU wait states here, once per slot
             if constexpr (i == 15) mfma_fence();
@@ -810,12 +644,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef K1_DBG_FENCE
             mfma_fence();
 #endif
-            valu(ic<i>{});
+            valu(i);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
     auto no_rd = [&](int) {};
-    auto no_valu = [&](auto) {};
+    auto no_valu = [&](int) {};
 
     // ---- the same two slots for BOTH blocks on one key tile: every K / V^T fragment read from
     // LDS feeds two MFMAs (block A, block B), which is what brings a slice's LDS + VALU issue
@@ -841,10 +675,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 if constexpr (j < 16) read_k(kslot, j);
                 else next_rd(j - 16);
             }
-            valu(ic<k>{});
+            valu(k);
             if constexpr (k == 31) mfma_fence();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((k & 7) == 7) K1_FSTAMP(k >> 3);
         });
     };
     auto slot_pv2 = [&](const Item &sA, const Item &sB, int vslot, Item &wA, Item &wB, auto &&valu,
@@ -871,9 +704,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 constexpr int bi = (k >> 2) & 1;  // 32..35 block A, 36..39 block B
                 mfma_pv<192 + 16 * bi>(ones, (bi ? sB : sA).p[k & 3], d);
             }
-            valu(ic<k>{});
+            valu(k);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((k & 7) == 7) K1_FSTAMP(4 + (k >> 3));
         });
     };
 
@@ -898,12 +730,21 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             it.sb[r] = vb ? it.sb[r] : -INFINITY;
         }
     };
-    // finish a pending item (its first kFirst ticks are done and its reference is settled: the step
-    // that produced it ended with decide_after_pv), then its P.V
+    auto softmax_plain = [&](Item &it, Block &blk, int e_from) {
+        if (e_from == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) max_step(it, j);
+            decide(it, blk);
+        }
+#pragma unroll
+        for (int n = 0; n < kTicks; ++n)
+            if (n >= e_from) tick(it, n);
+    };
+    // finish a pending item (its first kFirst ticks are done), then its P.V
     auto drain = [&](Item &it, Block &blk, auto bt, int vslot) {
         mfma_fence();
-#pragma unroll
-        for (int n = kFirst; n < kTicks; ++n) tick(it, blk, n);
+        softmax_plain(it, blk, kFirst);
+        rescale(it, bt);
         pv_plain(it, bt, vslot);
     };
     Item I0, I1;    // block A's two score register sets
@@ -913,13 +754,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) { it.sa[r] = -INFINITY; it.sb[r] = -INFINITY; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            it.p[i] = u32x4{0u, 0u, 0u, 0u};
-            // opaque: a constant that hipcc re-creates with v_mov right in front of an MFMA statement
-            // would be read before it has landed (VALU write -> MFMA operand hazard)
-            asm volatile("" : "+v"(it.p[i]));
-        }
-        it.mx = -INFINITY;
+        for (int i = 0; i < 4; ++i) it.p[i] = u32x4{0u, 0u, 0u, 0u};
+        it.mc = 0.0f; it.alpha = 1.0f; it.need = false; it.mx = -INFINITY;
         it.xf = -INFINITY; it.ya = 0.0f; it.yb = 0.0f;
     };
     clear_item(I0);
@@ -989,21 +825,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto single_step = [&](Item &cur, Item &nxt, auto masked) {
         stage_ids(t + 2);
         prime_k();
-        slot_qk(nxt, kA, ks_cur, cur,
-                [&](auto I) {
-                    valu_qk(cur, A, ic<kDealSingle>{}, I);
-                    st_w8(decltype(I)::value);
-                },
+        slot_qk(nxt, kA, ks_cur, cur, [&](int i) { valu_qk(cur, i); st_w8(i); },
                 [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(5);
         if constexpr (decltype(masked)::value) mask(nxt, A, (t + tile0) * kKV);
-        slot_pv(cur, kA, vs_prev, nxt,
-                [&](auto I) {
-                    valu_pv(nxt, A, ic<kDealSingle>{}, I);
-                    st_l8(decltype(I)::value);
-                },
-                no_rd);
-        decide_after_pv(nxt, A, kA);
+        rescale(cur, kA);
+        slot_pv(cur, kA, vs_prev, nxt, [&](int i) { valu_pv(nxt, A, i); st_l8(i); }, no_rd);
         K1_STAMP(6);
 #ifdef NVLLM_K1_STAMPS
         seg_sum[13] += 1;
@@ -1017,12 +844,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         stage_ids(t + 2);
         prime_k();
         slot_qk2(nA_, nB_, ks_cur, pA, pB,
-                 [&](auto K) {
-                     constexpr int k = decltype(K)::value;
-                     if constexpr (k & 1) valu_qk(pB, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
-                     else valu_qk(pA, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
+                 [&](int k) {
+                     valu_qk((k & 1) ? pB : pA, k >> 1);
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3) stage_w(ks_cur ^ 1, vs_next, k >> 2);
+                     if ((k & 3) == 3) stage_w(ks_cur ^ 1, vs_next, k >> 2);
 #endif
                  },
                  [&](int j) { read_v(vs_prev, j); });
@@ -1031,17 +856,17 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             mask(nB_, B, (t + tile0) * kKV);
             if (mask_a) mask(nA_, A, (t + tile0) * kKV);
         }
+        rescale(pA, kA);
+        rescale(pB, kB);
         slot_pv2(pA, pB, vs_prev, nA_, nB_,
-                 [&](auto K) {
-                     constexpr int k = decltype(K)::value;
-                     if constexpr (k & 1) valu_pv(nB_, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
-                     else valu_pv(nA_, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
+                 [&](int k) {
+                     if (k & 1) valu_pv(nB_, B, k >> 1);
+                     else valu_pv(nA_, A, k >> 1);
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3 && k < 32) stage_l(t + 2, k >> 2);
+                     if ((k & 3) == 3 && k < 32) stage_l(t + 2, k >> 2);
 #endif
                  },
                  no_rd);
-        decide_after_pv2(nA_, nB_);
         K1_STAMP(1);
 #ifdef NVLLM_K1_STAMPS
         seg_sum[12] += 1;
@@ -1094,9 +919,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     }
     // a drain after the last step still reads the V ring, which the epilogue reuses for O
     __syncthreads();
-#ifdef K1_ABL_NOBRANCH
-    asm volatile("" ::"s"(abl_sticky));
-#endif
 
 #ifdef NVLLM_K1_STAMPS
     float *lse_dbg = lse;

@@ -23,7 +23,9 @@ done
 /opt/rocm/bin/hipcc $FLAGS -Dlaunch_flash_attn_mfma=lab_unused_launch -Dflash_attn_mfma_supported=lab_unused_supported \
     -x hip -c $CSRC/flash_attn.hip -o $OUT/generic.o &
 pids="$pids $!"
+/opt/rocm/bin/hipcc $FLAGS -x hip -c $CSRC/launch_policy.cpp -o $OUT/launch_policy.o &
+pids="$pids $!"
 for p in $pids; do wait $p; done
 /opt/rocm/bin/hipcc $FLAGS -I$OUT -x hip -c $HERE/lab.cpp -o $OUT/lab.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -o $HERE/k1_lab $OUT/lab.o $OUT/generic.o $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -o $HERE/k1_lab $OUT/lab.o $OUT/generic.o $OUT/launch_policy.o $OBJS
 echo built $HERE/k1_lab
