@@ -1,6 +1,9 @@
 // Micro-benchmark: cost of LDS fragment reads (distinct destination registers, counted waits) and
 // staging stores in an MFMA gap, one wave per SIMD.
 #include <hip/hip_runtime.h>
+#ifndef UNROLL
+#define UNROLL 2
+#endif
 #include <cstdio>
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -24,7 +27,7 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4 *in, float *out, unsigne
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0)::"memory");
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < UNROLL; ++m) {
             // 4 gaps per group; reads of 4 distinct registers, waited at the end of the group
             if (MODE == 0) { G(MFMA); G(MFMA); G(MFMA); G(MFMA); }
             if (MODE == 1) { G(MFMA "ds_read_b128 %3, %19\n\t"); G(MFMA "ds_read_b128 %4, %19 offset:1024\n\t"); G(MFMA "ds_read_b128 %5, %19 offset:2048\n\t"); G(MFMA "ds_read_b128 %6, %19 offset:3072\n\ts_waitcnt lgkmcnt(2)\n\t"); }
@@ -51,14 +54,14 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4 *in, float *out, unsigne
     if (tid == 0) cyc[blockIdx.x] = c1 - c0;
 }
 template <int MODE> int run(const char *name, const u32x4 *in, float *out, unsigned long long *cyc) {
-    const int iters = 4000;
+    const int iters = 8000 / UNROLL;
     k<MODE><<<256, 256>>>(in, out, cyc, iters);
     CK(hipDeviceSynchronize());
     k<MODE><<<256, 256>>>(in, out, cyc, iters);
     CK(hipDeviceSynchronize());
     unsigned long long h[256]; CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
     double s = 0; for (int i = 0; i < 256; ++i) s += (double)h[i];
-    printf("%-66s %.2f cycles per gap\n", name, s / 256 / (8.0 * iters));
+    printf("%-66s %.2f cycles per gap\n", name, s / 256 / (4.0 * UNROLL * iters));
     return 0;
 }
 int main() {
