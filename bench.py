@@ -437,11 +437,11 @@ def run_producer(args, nv, dev, rank, world, steps, warmup, num_tokens):
 
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled
     per the gfx950 correction).  Counters cannot be read inside this process; None if the
     workload was not profiled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             return json.load(f)[key]["traffic_bytes"]
     except Exception:
         return None
