@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     int num_q_tiles, int pair_adjacent, float scale_log2e,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
     int max_blocks_per_seq, unsigned num_cache_chunks, unsigned char *__restrict__ split_ws,
-    int pack_shift) {
+    int pack_shift, int num_seqs) {
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
@@ -390,6 +390,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef NVLLM_K1_STAMPS
     unsigned long long seg_sum[16] = {0}, t_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#ifdef K1_RT  // wall-clock (100 MHz) start and end of the wave in slots 4 and 9
+    unsigned long long rt0_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
+#endif
 #endif
 
     // PAGED launches may pack the gp = 2^gsh query heads of a group into the rows: packed row rho
@@ -400,17 +404,26 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // one 64-key tile.  gsh = 0: a row is a position, as in the dense kernel.
     const int gsh = PAGED ? pack_shift : 0;
     const int gp = 1 << gsh;
-    // blockIdx.x = kvh + Hkv * (hg + Gq * J): kv head fastest; Gq head groups of gp heads per kv head
+    // blockIdx.x = kvh + Hkv * (hg + Gq * J): kv head fastest; Gq head groups of gp heads per kv head;
+    // blockIdx.y = batch element.  PAGED: blockIdx.x = kvh + Hkv * (hg + Gq * (b + num_seqs * J)), the
+    // pair index slowest over the WHOLE grid: a paged grid is sized for the worst alignment of the
+    // chunk (31 dead positions in front), so its highest pair often has no rows at all, and
+    // workgroups are dealt out in order, round-robin over the XCDs and then over each XCD's shader
+    // engines, waiting for a slot on the engine whose turn it is.  With J inside a sequence's
+    // index, live and empty workgroups alternated and all the live ones queued on half of the
+    // engines (T = 64 at 32Q/8KV: 128 of 256 CUs busy, measured with wall-clock stamps); with J
+    // slowest the empty ones come last and cost nothing.
     const int G = Hq / Hkv;
     const int Gq = G >> gsh;
     int bid = blockIdx.x;
     const int kvh = bid % Hkv;
     bid /= Hkv;
     const int hg = bid % Gq;
-    const int J = bid / Gq;
+    bid /= Gq;
+    const int J = PAGED ? bid / num_seqs : bid;
     const int hu = kvh + Hkv * hg;                          // unit (kv head, head group)
     const int hq = kvh * G + hg * gp + (c & (gp - 1));      // this lane's query head
-    const int b = blockIdx.y;
+    const int b = PAGED ? bid % num_seqs : blockIdx.y;
     // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
     // the tiling starts) and the dead rows in front of the first block (pos_shift)
     int kv_off = 0, pos_base = 0, pos_shift = 0;
@@ -553,7 +566,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const unsigned st_vw = (unsigned)(st_row0 * kVRow + 16 * (st_ch ^ (4 * (st_row0 & 3))));
     u32x4 st[8];
     unsigned pg_id[4], pg_idx[4];
-    // PAGED: fetch the four block ids of key tile t (early in a step; stage_l uses them later)
+    // PAGED: fetch the four block ids of key tile t; stage_idx(t) turns them into this thread's
+    // chunk indices a step later (the table read then has a whole step to land), stage_l uses those
     auto stage_ids = [&](int t) {
         if constexpr (PAGED) {
 #pragma unroll
@@ -561,15 +575,26 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 pg_id[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * (t + tile0), 0);
         }
     };
-    // fetch piece j of key tile t
+    auto stage_idx1 = [&](int t, int j) {
+        if constexpr (PAGED) {
+            unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
+            asm("v_mad_u32_u24 %0, %1, %2, %3"
+                : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
+            pg_idx[j] = (4 * (t + tile0) + j >= pg_blk_lim) ? 0xffffffffu : idx;
+        }
+    };
+    auto stage_idx = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_idx1(t, j);
+    };
+    // the ids in hand become tile t's indices, tile t+1's ids are requested
+    auto stage_next = [&](int t) {
+        stage_idx(t);
+        stage_ids(t + 1);
+    };
+    // fetch piece j of key tile t (PAGED: of the tile stage_idx was last called for)
     auto stage_l = [&](int t, int j) {
         if constexpr (PAGED) {
-            if (j < 4) {
-                unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
-                asm("v_mad_u32_u24 %0, %1, %2, %3"
-                    : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
-                pg_idx[j] = (4 * (t + tile0) + j >= pg_blk_lim) ? 0xffffffffu : idx;
-            }
             st[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
                                                                       (int)pg_idx[j & 3], 0, 0, 0));
         } else {
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = st[j];
     };
     auto stage_load = [&](int t) {
-        stage_ids(t);
+        stage_next(t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage_l(t, j);
     };
@@ -928,6 +953,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     clear_item(J1);
 
     // ---- prologue: tile 0 into slot 0, V slot 2 ("tile -1") zeroed, tile 1 in flight
+    stage_ids(0);
     stage_load(0);
     commit_q(kA, qa);
     commit_q(kB, qb);
@@ -968,16 +994,26 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         stage_write(ks_cur ^ 1, vs_next);
         stage_load(t + 2);
     };
-    // ... or dealt out over the MFMA gaps of the pipelined bodies
     // ... or dealt out over the MFMA gaps of the pipelined bodies, into slices that issue no
-    // fragment reads (2, 3 mod 4, and the four l slices of a P.V slot)
+    // fragment reads.  Either way a step starts with tile t+1 in the staging registers (landed or
+    // in flight) and tile t+2's block ids in pg_id, and ends one tile further.
+    // Two-block steps: the eight writes in the QK^T slot, the eight fetches in the P.V slot, so the
+    // registers are free in between (the step's register peak) and a fetch has one slot, about 1700
+    // cycles, to land.  One-block steps are half as long and have registers to spare: position
+    // p = 0..7 of a slot writes (p even) piece p/2 to LDS or refills (p odd) the same registers with
+    // that piece of tile t+2 -- K pieces in the QK^T slot, V pieces in the P.V slot -- so a fetch
+    // has the whole step to land (with one slot, about 950 cycles, HBM-streaming launches waited
+    // in every step: 2735 cycles a step against 1960 from L2).
 #ifdef K1_ABL_NOSTAGE
-    auto st_w8 = [&](int) {};
-    auto st_l8 = [&](int) {};
+    auto st_pos = [&](int, int) {};
 #else
-    auto st_w8 = [&](int i) { if ((i & 2) && i < 16) stage_w(ks_cur ^ 1, vs_next, (i >> 2) * 2 + (i & 1)); };
-    auto st_l8 = [&](int i) { if ((i & 2) && i < 16) stage_l(t + 2, (i >> 2) * 2 + (i & 1)); };
+    auto st_pos = [&](int p, int base) {
+        if (p & 1) stage_l(t + 2, base + (p >> 1));
+        else stage_w(ks_cur ^ 1, vs_next, base + (p >> 1));
+    };
 #endif
+    auto st_qk8 = [&](int i) { if ((i & 2) && i < 16) st_pos((i >> 2) * 2 + (i & 1), 0); };
+    auto st_pv8 = [&](int i) { if ((i & 2) && i < 16) st_pos((i >> 2) * 2 + (i & 1), 4); };
     auto prime_k = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) read_k(ks_cur, j);
@@ -987,12 +1023,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // multiplied.  MASKED (A's last tile): the fresh scores are masked between the two slots, the
     // rest of the step is the same, and the caller drains `nxt` afterwards.
     auto single_step = [&](Item &cur, Item &nxt, auto masked) {
-        stage_ids(t + 2);
+        stage_next(t + 2);
         prime_k();
         slot_qk(nxt, kA, ks_cur, cur,
                 [&](auto I) {
                     valu_qk(cur, A, ic<kDealSingle>{}, I);
-                    st_w8(decltype(I)::value);
+                    st_qk8(decltype(I)::value);
                 },
                 [&](int j) { read_v(vs_prev, j); });
         K1_STAMP(5);
@@ -1000,7 +1036,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         slot_pv(cur, kA, vs_prev, nxt,
                 [&](auto I) {
                     valu_pv(nxt, A, ic<kDealSingle>{}, I);
-                    st_l8(decltype(I)::value);
+                    st_pv8(decltype(I)::value);
                 },
                 no_rd);
         decide_after_pv(nxt, A, kA);
@@ -1014,7 +1050,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // both blocks: QK^T of tile t into (nA_, nB_) while the pending items (pA, pB: tile t-1) are
     // finished and multiplied.  MASKED = block B's last tile (and block A's too when mask_a).
     auto dual_step = [&](Item &pA, Item &pB, Item &nA_, Item &nB_, auto masked, bool mask_a) {
-        stage_ids(t + 2);
         prime_k();
         slot_qk2(nA_, nB_, ks_cur, pA, pB,
                  [&](auto K) {
@@ -1037,7 +1072,11 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_pv(nB_, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_pv(nA_, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3 && k < 32) stage_l(t + 2, k >> 2);
+                     if constexpr ((k & 3) == 3 && k < 32) {
+                         if constexpr ((k >> 2) < 4) stage_idx1(t + 2, k >> 2);
+                         stage_l(t + 2, k >> 2);
+                     }
+                     if constexpr (k == 35) stage_ids(t + 3);
 #endif
                  },
                  no_rd);
@@ -1125,7 +1164,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 const int tile = vr / kQTile;
                 const int ur = ((tile == tile_long && tile_long != tile_short) ? kQTile : 0) + (vr & (kQTile - 1));
                 const int Hu = Hkv * Gq;
-                const size_t pairs_max = gridDim.x / (unsigned)Hu;
+                const size_t pairs_max = gridDim.x / (unsigned)(Hu * num_seqs);
                 unsigned char *slot = split_ws + ((((size_t)b * Hu + hu) * pairs_max + J) * gridDim.z + blockIdx.z) *
                                                      (size_t)kSplitSlotBytes;
                 __bf16 *op = reinterpret_cast<__bf16 *>(slot) + ur * kD + 4 * h;
@@ -1182,6 +1221,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     store(B, kB, liveB);
 #ifdef NVLLM_K1_STAMPS
     K1_STAMP(3);  // epilogue
+#ifdef K1_RT
+    seg_sum[4] = rt0_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_sum[9])::"memory");
+#endif
     if (lse_dbg && lane == 0) {
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(lse_dbg) +
                                   ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 16);
@@ -1302,11 +1345,11 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     if (a.causal)
         flash_attn_mfma_kernel<true, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0);
     else
         flash_attn_mfma_kernel<false, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0);
     return hipGetLastError();
 }
 
@@ -1391,11 +1434,11 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
         if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15u) != 0)
             return hipErrorInvalidValue;
         auto ws = static_cast<unsigned char *>(a.workspace);
-        const dim3 grid((unsigned)(g.pairs * g.units), (unsigned)a.num_seqs, (unsigned)parts);
+        const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs), 1u, (unsigned)parts);
         flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(
             q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
             pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, ws,
-            g.gsh);
+            g.gsh, a.num_seqs);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         const dim3 mgrid(2 * kQTile / 4, (unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
@@ -1404,11 +1447,15 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
             pair_adjacent, parts, g.gsh);
         return hipGetLastError();
     }
-    const dim3 grid((unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
+    const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs));
+    float *lse_arg = nullptr;
+#ifdef NVLLM_K1_STAMPS  // diagnostic build only: the stamp buffer rides in the (unused) workspace
+    lse_arg = static_cast<float *>(a.workspace);
+#endif
     flash_attn_mfma_kernel<true, true, false><<<grid, block, 0, stream>>>(
-        q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
+        q, kc, vc, o, lse_arg, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
         pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, nullptr,
-        g.gsh);
+        g.gsh, a.num_seqs);
     return hipGetLastError();
 }
 

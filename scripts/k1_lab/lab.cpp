@@ -18,11 +18,13 @@
 
 using nvllm::kernels::DType;
 using nvllm::kernels::FlashAttnArgs;
+using nvllm::kernels::PagedAttnArgs;
 
 namespace nvllm {
 namespace kernels {
 #define LAB_VARIANT(name)                                                   \
     hipError_t launch_##name(const FlashAttnArgs &a, hipStream_t stream);  \
+    hipError_t launch_paged_##name(const PagedAttnArgs &a, hipStream_t stream); \
     bool supported_##name(const FlashAttnArgs &a);
 #include "variants.inc"
 #undef LAB_VARIANT
@@ -36,9 +38,10 @@ struct Variant {
     const char *name;
     hipError_t (*launch)(const FlashAttnArgs &, hipStream_t);
     bool (*supported)(const FlashAttnArgs &);
+    hipError_t (*launch_paged)(const PagedAttnArgs &, hipStream_t);
 };
 static const Variant kVariants[] = {
-#define LAB_VARIANT(name) {#name, nvllm::kernels::launch_##name, nvllm::kernels::supported_##name},
+#define LAB_VARIANT(name) {#name, nvllm::kernels::launch_##name, nvllm::kernels::supported_##name, nvllm::kernels::launch_paged_##name},
 #include "variants.inc"
 #undef LAB_VARIANT
 };
@@ -65,6 +68,98 @@ static float bf2f(uint16_t h) {
     return f;
 }
 
+// LAB_PAGED=T: the paged variant (K1 over the cache): B sequences x S cached tokens, T new tokens
+// each, identity block tables; timing and stamps only (correctness is the test suite's job)
+static int paged_main(int N, int ctx, int Hq, int Hkv, int T, int rounds, int iters) {
+    const int D = 128, bs = 16, nblk = ctx / bs;
+    const size_t nq = (size_t)N * T * Hq * D, nc = (size_t)N * nblk * bs * Hkv * D;
+    std::vector<uint16_t> hq(nq), hc(nc);
+    std::mt19937 rng(99);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (auto &x : hq) x = f2bf(nd(rng));
+    for (size_t i = 0; i < nc; ++i) hc[i] = f2bf(nd(rng));
+    std::vector<int32_t> tab((size_t)N * nblk), cl(N, ctx);
+    for (int s = 0; s < N; ++s)
+        for (int i = 0; i < nblk; ++i) tab[(size_t)s * nblk + i] = s * nblk + ((i * 37) % nblk);
+    uint16_t *dq, *dk, *dv, *dout; int32_t *dtab, *dcl;
+    CK(hipMalloc(&dq, nq * 2)); CK(hipMalloc(&dk, nc * 2)); CK(hipMalloc(&dv, nc * 2)); CK(hipMalloc(&dout, nq * 2));
+    CK(hipMalloc(&dtab, tab.size() * 4)); CK(hipMalloc(&dcl, cl.size() * 4));
+    CK(hipMemcpy(dq, hq.data(), nq * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dk, hc.data(), nc * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dv, hc.data(), nc * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dcl, cl.data(), cl.size() * 4, hipMemcpyHostToDevice));
+    const size_t nwaves = (size_t)N * 64 * 4;  // grid.x <= 64 here
+    unsigned long long *dd;
+    CK(hipMalloc(&dd, nwaves * 128));
+    PagedAttnArgs a{};
+    a.q = dq; a.k_cache = dk; a.v_cache = dv; a.block_tables = dtab; a.context_lens = dcl; a.out = dout;
+    a.workspace = nullptr; a.workspace_bytes = 0; a.num_seqs = N; a.num_new_tokens = T; a.num_heads = Hq;
+    a.num_kv_heads = Hkv; a.head_dim = D; a.block_size = bs; a.max_blocks_per_seq = nblk;
+    a.num_cache_blocks = (int64_t)N * nblk; a.scale = 1.0f / sqrtf((float)D);
+    const double flops = 4.0 * N * T * Hq * (double)ctx * D;
+    printf("paged shape N=%d ctx=%d T=%d Hq=%d Hkv=%d (%.2f GFLOP)\n", N, ctx, T, Hq, Hkv, flops / 1e9);
+    const int nv = sizeof(kVariants) / sizeof(kVariants[0]);
+    for (int vi = 0; vi < nv; ++vi) {
+        const Variant &v = kVariants[vi];
+        if (strncmp(v.name, "stamp", 5) != 0) continue;
+        CK(hipMemset(dd, 0, nwaves * 128));
+        PagedAttnArgs sa = a;
+        sa.workspace = dd;  // stamp builds take the stamp buffer here
+        for (int i = 0; i < 3; ++i) CK(v.launch_paged(sa, 0));
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hd(nwaves * 16);
+        CK(hipMemcpy(hd.data(), dd, nwaves * 128, hipMemcpyDeviceToHost));
+        double sum[16] = {0}; size_t n = 0;
+        for (size_t w = 0; w < nwaves; ++w) {
+            if (hd[w * 16 + 15] == 0) continue;
+            for (int i = 0; i < 16; ++i) sum[i] += (double)hd[w * 16 + i];
+            ++n;
+        }
+        if (!n) continue;
+        if (strstr(v.name, "rt")) {  // wall-clock stamps (10 ns ticks) in slots 4 / 9
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t w = 0; w < nwaves; ++w)
+                if (hd[w * 16 + 15]) { t0 = std::min(t0, hd[w * 16 + 4]); t1 = std::max(t1, hd[w * 16 + 9]); }
+            double dur = 0; int late[6] = {0};
+            for (size_t w = 0; w < nwaves; ++w) {
+                if (!hd[w * 16 + 15]) continue;
+                dur += (double)(hd[w * 16 + 9] - hd[w * 16 + 4]);
+                const double off = (double)(hd[w * 16 + 4] - t0) * 0.01;
+                ++late[off < 5 ? 0 : off < 20 ? 1 : off < 40 ? 2 : off < 60 ? 3 : off < 100 ? 4 : 5];
+            }
+            printf("%-14s wall: first start .. last end %.1f us, mean wave %.1f us; start offsets <5us:%d <20:%d <40:%d <60:%d <100:%d more:%d\n",
+                   v.name, (double)(t1 - t0) * 0.01, dur / n * 0.01, late[0], late[1], late[2], late[3], late[4], late[5]);
+            sum[4] = sum[9] = 0;
+        }
+        printf("%-14s stamps over %zu waves: steps/wave %.1f, c12=%.1f c13=%.1f\n", v.name, n, sum[15] / n, sum[12] / n, sum[13] / n);
+        printf("%-14s   cycles per wave: ", v.name);
+        double tot = 0;
+        for (int i = 0; i < 12; ++i) { printf("s%d=%.0f ", i, sum[i] / n); tot += sum[i]; }
+        printf("total=%.0f\n", tot / n);
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int vi = 0; vi < nv; ++vi) {
+        const Variant &v = kVariants[vi];
+        PagedAttnArgs sa = a;
+        if (strncmp(v.name, "stamp", 5) == 0) sa.workspace = dd;
+        std::vector<double> t;
+        for (int r = 0; r < rounds + 1; ++r) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) CK(v.launch_paged(sa, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) t.push_back(ms / iters);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-14s median %8.1f us  %7.1f TF\n", v.name, t[t.size() / 2] * 1e3, flops / (t[t.size() / 2] * 1e-3) / 1e12);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     int B = 1, S = 4096, Hq = 16, Hkv = 8, causal = 1, rounds = 5, iters = 20, check = 1, spike = 0;
     for (int i = 1; i < argc; ++i) {
@@ -78,6 +173,7 @@ int main(int argc, char **argv) {
         else if (k == "check") check = v; else if (k == "spike") spike = v;
     }
     const int D = 128;
+    if (getenv("LAB_PAGED")) return paged_main(B, S, Hq, Hkv, atoi(getenv("LAB_PAGED")), rounds, iters);
     const size_t nq = (size_t)B * S * Hq * D, nk = (size_t)B * S * Hkv * D;
     std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
     std::mt19937 rng(1234);
