@@ -84,7 +84,8 @@ constexpr int kD = 128;          // head_dim of the fast path
 constexpr int kBS = 16;          // block_size of the fast path
 constexpr int kRowBytes = kD * 2;
 constexpr int kTileBlocks = 2;   // 32 tokens per tile
-constexpr int kLdsPerWave = kTileBlocks * kBS * kRowBytes;  // 8 KiB
+constexpr int kLdsTile = kTileBlocks * kBS * kRowBytes;     // 8 KiB: one tile of K or of V
+constexpr int kLdsPerWave = 2 * kLdsTile;                    // the wave's K image and V image
 constexpr int64_t kMultiTileMinTokens = 384 * 1024;  // see paged_attn_fast_path
 constexpr int64_t kMultiTileMinContext = 16384;
 constexpr int kMaxFastRows = 48;  // query rows (T * Hq/Hkv) per kv head the decode kernel takes
@@ -102,7 +103,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 
 struct TileRegs {
-    u32x4 k[kTileBlocks][4];  // [block][k-step]   MFMA A fragments of K
+    u32x4 k[kTileBlocks][4];  // [block][row quad] coalesced rows of K
     u32x4 v[kTileBlocks][4];  // [block][row quad] coalesced rows of V
 };
 
@@ -166,15 +167,20 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
 
     const int64_t block_bytes = (int64_t)kBS * Hkv * kRowBytes;
     const unsigned row_stride = (unsigned)Hkv * kRowBytes;
-    const unsigned k_lane_off = (unsigned)c * row_stride + (unsigned)kvh * kRowBytes + 16u * g;
     const unsigned v_lane_off = (unsigned)g * row_stride + (unsigned)kvh * kRowBytes + 16u * c;
     // LDS addresses.  Row r of block b sits at b*4096 + r*256; its 16-byte chunk
     // ch is stored at chunk position ch ^ (2*(r&7)) (conflict-free tr reads).
     unsigned lds_wr[4];  // write address of V row (4i+g), chunk c
+    // K image (second half of the wave's LDS): chunk ch of row r at position ch ^ r, so that the
+    // row-per-lane A-fragment reads below (16 lanes, 16 rows, the same chunk) hit 16 different
+    // positions, as the whole-row writes do.
+    unsigned lds_kwr[4], lds_krd[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 4 * i + g;
         lds_wr[i] = (unsigned)(r * kRowBytes + 16 * (c ^ (2 * (r & 7))));
+        lds_kwr[i] = (unsigned)(kLdsTile + r * kRowBytes + 16 * (c ^ r));
+        lds_krd[i] = (unsigned)(kLdsTile + c * kRowBytes + 16 * ((4 * i + g) ^ c));  // k-step i
     }
     // transposed read: lane c = 4*qq + p of group g addresses row 4g+qq,
     // elements 16*dt + 4p .. +3  => chunk 2*dt + (p>>1), byte 8*(p&1) in chunk.
@@ -206,10 +212,15 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
         const int64_t pid[kTileBlocks] = {clamp_id(p0), clamp_id(p1)};
 #pragma unroll
         for (int b = 0; b < kTileBlocks; ++b) {
-            const unsigned char *kb = k_cache + pid[b] * block_bytes + k_lane_off;
+            // K and V alike: an instruction reads four whole 256-byte rows.  (K used to be read
+            // straight into the MFMA's row-per-lane layout, 64 bytes of 16 rows per instruction:
+            // every 128-byte line was then asked for twice, and where the reads are served by L2
+            // -- shared prefixes -- L2's request rate was the bound: 1024 shared tokens x 256
+            // sequences 88 -> 56 us.)
+            const unsigned char *kb = k_cache + pid[b] * block_bytes + v_lane_off;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const u32x4 *ptr = reinterpret_cast<const u32x4 *>(kb + 64 * s);
+                const u32x4 *ptr = reinterpret_cast<const u32x4 *>(kb + (size_t)(4 * s) * row_stride);
                 tr.k[b][s] = STREAM ? __builtin_nontemporal_load(ptr) : *ptr;
             }
         }
@@ -243,6 +254,17 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
         const int tok0 = (blk_begin + kTileBlocks * t) * kBS;
         const bool tail = (tok0 + kTileBlocks * kBS > first_masked_tok) ||
                           (blk_begin + kTileBlocks * t + 1 >= blk_end);
+        // ---- K through the wave's LDS image into A fragments: lane (g,c) = K[row c][32s+8g .. +7]
+#pragma unroll
+        for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<u32x4 *>(lds + b * (kBS * kRowBytes) + lds_kwr[i]) = tr.k[b][i];
+#pragma unroll
+        for (int b = 0; b < kTileBlocks; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                tr.k[b][ks] = *reinterpret_cast<const u32x4 *>(lds + b * (kBS * kRowBytes) + lds_krd[ks]);
         // ---- S^T = K Q^T
         f32x4 s[NQT][kTileBlocks];
 #pragma unroll
@@ -381,8 +403,16 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
             compute_tile(tb, t + 1);
         }
     };
+    // Half of the sequences (every other group of eight: workgroups go round-robin over the eight
+    // XCDs, so each XCD's L2 sees both kinds) walk their private tiles first and the shared prefix
+    // last; online softmax does not care about the order.  With everybody on the prefix first, HBM
+    // sat idle while 256 workgroups drew the same 4 MiB from L2, and then all of them queued on
+    // HBM: config 4 took the sum of the two phases, now the phases of the two halves overlap.
+    const bool private_first = NT && nshared > 0 && nshared < ntiles && ((seq >> 3) & 1);
+    const int cut = private_first ? ntiles : nshared;  // private tiles [nshared, cut) go first
+    run_tiles(std::true_type{}, nshared, cut);
     run_tiles(std::false_type{}, 0, nshared);
-    run_tiles(std::true_type{}, nshared, ntiles);
+    run_tiles(std::true_type{}, cut, ntiles);
 
     // ---- epilogue
 #pragma unroll
