@@ -568,13 +568,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     unsigned pg_id[4], pg_idx[4];
     // PAGED: fetch the four block ids of key tile t; stage_idx(t) turns them into this thread's
     // chunk indices a step later (the table read then has a whole step to land), stage_l uses those
-    auto stage_ids = [&](int t) {
+    auto stage_ids_to = [&](unsigned (&dst)[4], int t) {
         if constexpr (PAGED) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                pg_id[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * (t + tile0), 0);
+                dst[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * (t + tile0), 0);
         }
     };
+    auto stage_ids = [&](int t) { stage_ids_to(pg_id, t); };
     auto stage_idx1 = [&](int t, int j) {
         if constexpr (PAGED) {
             unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
@@ -593,23 +594,25 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         stage_ids(t + 1);
     };
     // fetch piece j of key tile t (PAGED: of the tile stage_idx was last called for)
-    auto stage_l = [&](int t, int j) {
+    auto stage_l_to = [&](u32x4 (&dst)[8], int t, int j) {
         if constexpr (PAGED) {
-            st[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
-                                                                      (int)pg_idx[j & 3], 0, 0, 0));
+            dst[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
+                                                                       (int)pg_idx[j & 3], 0, 0, 0));
         } else {
             const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
-            st[j] = __builtin_bit_cast(
+            dst[j] = __builtin_bit_cast(
                 u32x4, __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc, st_voff, soff, 0));
         }
     };
+    auto stage_l = [&](int t, int j) { stage_l_to(st, t, j); };
     // write piece j to K ring slot kslot / V ring slot vslot
-    auto stage_w = [&](int kslot, int vslot, int j) {
+    auto stage_w_from = [&](const u32x4 (&src)[8], int kslot, int vslot, int j) {
         if (j < 4)
-            *reinterpret_cast<u32x4 *>(lds + st_kw + kslot * kKTile + j * 16 * kKRow) = st[j];
+            *reinterpret_cast<u32x4 *>(lds + st_kw + kslot * kKTile + j * 16 * kKRow) = src[j];
         else
-            *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = st[j];
+            *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = src[j];
     };
+    auto stage_w = [&](int kslot, int vslot, int j) { stage_w_from(st, kslot, vslot, j); };
     auto stage_load = [&](int t) {
         stage_next(t);
 #pragma unroll
@@ -947,25 +950,37 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         it.mx = -INFINITY;
         it.xf = -INFINITY; it.ya = 0.0f; it.yb = 0.0f;
     };
-    clear_item(I0);
-    clear_item(I1);
-    clear_item(J0);
-    clear_item(J1);
-
-    // ---- prologue: tile 0 into slot 0, V slot 2 ("tile -1") zeroed, tile 1 in flight
-    stage_ids(0);
-    stage_load(0);
-    commit_q(kA, qa);
-    commit_q(kB, qb);
+    // ---- prologue: tile 0 into slot 0, V slot 2 ("tile -1") zeroed, tile 1 in flight.  Tiles 0 and
+    // 1 are requested together (tile 0 into registers of its own, which only live here, where
+    // nothing else does yet), and so are their block ids: one table round trip and one K/V round
+    // trip before the first step instead of two of each.
     {
+        u32x4 st0[8];
+        unsigned pg_id1[4] = {0u, 0u, 0u, 0u};
+        stage_ids(0);
+        stage_ids_to(pg_id1, 1);
+        stage_idx(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_l_to(st0, 0, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pg_id[i] = pg_id1[i];
+        stage_next(1);  // tile 1's indices, tile 2's ids
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_l(1, j);
+        commit_q(kA, qa);
+        commit_q(kB, qb);
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage_w_from(st0, 0, 0, j);
     }
-    stage_write(0, 0);
-    stage_load(1);
     __syncthreads();
+    clear_item(I0);
+    clear_item(I1);
+    clear_item(J0);
+    clear_item(J1);
 
     int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
     int ks_cur = 0;                            // K ring slot of tile t
