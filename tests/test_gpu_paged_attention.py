@@ -239,6 +239,29 @@ def test_adaptive_cache_policy_is_invisible(dev, policy, nt, prefix_blocks, spli
     assert_attention_close(got, want)
 
 
+@pytest.mark.parametrize("T", [1, 4, 8, 12])
+@pytest.mark.parametrize("prefix_blocks,splits", [(8, 1), (9, 1), (8, 2), (30, 1)])
+def test_private_tiles_first_walk(dev, policy, T, prefix_blocks, splits):
+    # sequences 8..15, 24..31 ... walk their private tiles before the shared prefix (config 4's
+    # overlap of L2 and HBM phases): same result as the oracle's front-to-back walk, for one to
+    # three query tiles, a prefix that ends inside a 2-block tile, splits, contexts that end inside
+    # the prefix's last tile or barely past it, and the causal tail of T > 1
+    policy.setenv("NVLLM_PAGED_NT", "1")
+    policy.setenv("NVLLM_PAGED_SPLITS", str(splits))
+    Hq, Hkv, D, bs = 32, 8, 128, 16
+    rng = np.random.default_rng(1000 * T + prefix_blocks)
+    n = 20
+    ctx_lens = [16 * prefix_blocks + (1 + 37 * i) % 400 + T for i in range(n)]
+    ctx_lens[9] = 16 * prefix_blocks + T          # nothing but the prefix and the new tokens
+    ctx_lens[10] = 16 * prefix_blocks + 17 + T    # one private block and a bit
+    kc, vc, tables = make_paged_case(rng, ctx_lens, 700, bs, Hkv, D, shared_prefix_blocks=prefix_blocks)
+    q = bf16_randn(rng, (n, T, Hq, D))
+    scale = 1.0 / math.sqrt(D)
+    got = _run_batched(dev, q, kc, vc, tables, ctx_lens, scale, max_blocks=64)
+    want = oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, scale)
+    assert_attention_close(got, want)
+
+
 def test_zero_context_rows_are_zero(dev):
     Hq, Hkv, D, bs = 32, 8, 128, 16
     rng = np.random.default_rng(0)

@@ -137,6 +137,19 @@ def test_generic_path(dev, dtype, D):
     assert np.array_equal(gvc, wvc)
 
 
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float32, 128), (torch.float32, 32)])
+def test_in_place_equals_out_of_place(dev, dtype, D):
+    """q_out may be q itself (the default): both K5 kernels must give the same bits either way
+    (the fast path and the generic one)."""
+    n, Hq, Hkv, nb, bs, max_pos, eps = 45, 8, 2, 12, 4, 300, 1e-6
+    rng = np.random.default_rng(1000 + D)
+    q, k, v, qw, kw, pos, slots, rot, cos, sin = _case(rng, dev, dtype, n, Hq, Hkv, D, nb, bs, max_pos)
+    a = _run(dev, dtype, q, k, v, qw, kw, eps, rot, pos, slots, nb, bs, in_place=True)
+    b = _run(dev, dtype, q, k, v, qw, kw, eps, rot, pos, slots, nb, bs, in_place=False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_reference_known_answer_through_the_kernel(dev):
     # model_norm_test.rs:47-72 ([1,2,3,4] -> x / rms, < 1e-5) at position 0, where RoPE is the
     # identity (cos 1, sin 0); then position 5 must change the values (model_rope_test.rs:72-99)
