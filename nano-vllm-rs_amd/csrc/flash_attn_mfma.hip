@@ -72,7 +72,18 @@ constexpr int kVRow = 256, kVTile = kKV * kVRow;  // 16 KiB, swizzled
 constexpr int kKRow = 272, kKTile = kKV * kKRow;  // 17 KiB, padded rows (conflict-free b128 reads)
 constexpr int kVRing = 3, kKRing = 2;
 constexpr int kKBase = kVRing * kVTile;
-constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 83,968 B
+// Dense launches: K/V tiles go HBM -> LDS directly (buffer_load ... lds, no staging
+// registers, no ds_write): an instruction writes 1 KiB linearly, so the K image has plain 256-byte
+// rows with the chunks XOR-swizzled by the row (through each lane's SOURCE address), and a third
+// slot so that a tile can be requested two steps before it is read.
+#ifdef K1_NO_DMA  // lab only: the register-staged path for A/B runs
+constexpr bool kDmaDense = false;
+#else
+constexpr bool kDmaDense = true;
+#endif
+constexpr int kKRowD = 256, kKTileD = kKV * kKRowD, kKRingD = 3;
+constexpr int kLdsBytes =
+    kKBase + (kDmaDense && kKRingD * kKTileD > kKRing * kKTile ? kKRingD * kKTileD : kKRing * kKTile);
 constexpr int kORow = 272, kOStage = 32 * kORow;  // epilogue: O rows of a block, padded
 static_assert(2 * kWaves * kOStage <= kLdsBytes, "O staging must fit the K/V rings");
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
@@ -381,6 +392,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    constexpr bool DMA = kDmaDense && !PAGED;
+    constexpr int KTILE = DMA ? kKTileD : kKTile;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -566,6 +579,32 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const unsigned st_vw = (unsigned)(st_row0 * kVRow + 16 * (st_ch ^ (4 * (st_row0 & 3))));
     u32x4 st[8];
     unsigned pg_id[4], pg_idx[4];
+    // DMA: piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
+    // instruction: lane L writes LDS bytes [16 L, 16 L + 16) of the piece's 1 KiB, i.e. position
+    // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
+    unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
+    u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};
+    if constexpr (DMA) {
+        const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
+        dma_vv = rin * row_bytes + 16u * (pos ^ (4u * rin));
+        const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
+        dma_krs = u32x4{(unsigned)ka, (unsigned)(ka >> 32) & 0xffffu, kv_bytes, 0x00020000u};
+        dma_vrs = u32x4{(unsigned)va, (unsigned)(va >> 32) & 0xffffu, kv_bytes, 0x00020000u};
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
+    auto dma_piece = [&](int t, int kslot, int vslot, int j) {
+        const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)(j & 3);
+        const unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
+        const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * KTILE) : (unsigned)(vslot * kVTile)) + r0 * 256u;
+        if (j < 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         : : "s"(dst), "v"(dma_kv[j]), "s"(dma_krs), "s"(soff) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         : : "s"(dst), "v"(dma_vv), "s"(dma_vrs), "s"(soff) : "memory");
+    };
     // PAGED: fetch the four block ids of key tile t; stage_idx(t) turns them into this thread's
     // chunk indices a step later (the table read then has a whole step to land), stage_l uses those
     auto stage_ids_to = [&](unsigned (&dst)[4], int t) {
@@ -626,6 +665,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // ---- LDS read addresses
     // K A-fragment (u, ks): row 32u + c, 16-byte chunk 2ks + h of a padded row
     const unsigned k_rd = (unsigned)(kKBase + c * kKRow + 16 * h);
+    unsigned k_rd8[8];  // DMA image: chunk 2ks + h of row c (mod 16) sits at position (2ks + h) ^ (c & 15)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) k_rd8[ks] = (unsigned)(kKBase + c * kKRowD + 16 * ((2 * ks + h) ^ (c & 15)));
     // V^T A-fragment (transposed read): 16-lane group g16 = lane>>4 covers d chunk
     // 4dt + 2(g16&1) + (p>>1), key rows 16sp + 4h + qq (+8 for the second read)
     const int c16 = lane & 15, qq = c16 >> 2, pp = c16 & 3, g16 = lane >> 4;
@@ -642,8 +684,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     u32x4 fr[8];
     // K fragment i (u = i>>3, ks = i&7) of a QK slot
     auto read_k = [&](int slot, int i) {
-        const unsigned char *kt = lds + k_rd + slot * kKTile;
-        fr[i & 7] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
+        if constexpr (DMA) {
+            fr[i & 7] = *reinterpret_cast<const u32x4 *>(lds + k_rd8[i & 7] + slot * KTILE + (i >> 3) * 32 * kKRowD);
+        } else {
+            const unsigned char *kt = lds + k_rd + slot * kKTile;
+            fr[i & 7] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
+        }
     };
     // V^T fragment i (dt = i>>2, sp = i&3) of a PV slot
     auto read_v = [&](int slot, int i) {
@@ -954,7 +1000,22 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // 1 are requested together (tile 0 into registers of its own, which only live here, where
     // nothing else does yet), and so are their block ids: one table round trip and one K/V round
     // trip before the first step instead of two of each.
-    {
+    if constexpr (DMA) {
+        // K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0; V slot 2 ("tile -1") zeroed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j);
+        commit_q(kA, qa);
+        commit_q(kB, qb);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         u32x4 st0[8];
         unsigned pg_id1[4] = {0u, 0u, 0u, 0u};
         stage_ids(0);
@@ -984,6 +1045,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 
     int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
     int ks_cur = 0;                            // K ring slot of tile t
+    int ks_n1 = 1, ks_n2 = 2;                  // DMA: K ring slots of tiles t+1, t+2
     K1_STAMP(2);  // kernel start .. first step (Q load, first two tiles)
     // Every wave runs the same number of steps (nsteps), one barrier each, but walks them in its
     // own phases -- separate loops, so that each hot loop is one straight body whose registers
@@ -991,6 +1053,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     int t = 0;
     // end of a step: publish tile t+1 (written during this step), rotate the rings
     auto step_end = [&]() {
+        // DMA: the wave's 8 pieces of this step (K of tile t+2, V of tile t+1) may stay in flight,
+        // the 8 of the step before (K of t+1, V of t: read in the next step) must have landed
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
         K1_STAMP(11);  // barrier
 #ifdef NVLLM_K1_STAMPS
@@ -1000,14 +1065,28 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         vs_prev = vs_cur;
         vs_cur = vs_next;
         vs_next = x;
-        ks_cur ^= 1;
+        if constexpr (DMA) {
+            const int y = ks_cur;
+            ks_cur = ks_n1;
+            ks_n1 = ks_n2;
+            ks_n2 = y;
+        } else {
+            ks_cur ^= 1;
+        }
         ++t;
     };
     // staging of a step, all at once (un-pipelined steps): tile t+1 (fetched during step t-1) goes
     // to LDS, then tile t+2 is fetched into the same registers
     auto stage_step = [&]() {
-        stage_write(ks_cur ^ 1, vs_next);
-        stage_load(t + 2);
+        if constexpr (DMA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j);
+#pragma unroll
+            for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j);
+        } else {
+            stage_write(ks_cur ^ 1, vs_next);
+            stage_load(t + 2);
+        }
     };
     // ... or dealt out over the MFMA gaps of the pipelined bodies, into slices that issue no
     // fragment reads.  Either way a step starts with tile t+1 in the staging registers (landed or
@@ -1023,8 +1102,15 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto st_pos = [&](int, int) {};
 #else
     auto st_pos = [&](int p, int base) {
-        if (p & 1) stage_l(t + 2, base + (p >> 1));
-        else stage_w(ks_cur ^ 1, vs_next, base + (p >> 1));
+        if constexpr (DMA) {  // K pieces of tile t+2 in the QK^T slot, V pieces of tile t+1 in the P.V slot
+            if (p < 4) {
+                if (base == 0) dma_piece(t + 2, ks_n2, 0, p);
+                else dma_piece(t + 1, 0, vs_next, 4 + p);
+            }
+        } else {
+            if (p & 1) stage_l(t + 2, base + (p >> 1));
+            else stage_w(ks_cur ^ 1, vs_next, base + (p >> 1));
+        }
     };
 #endif
     auto st_qk8 = [&](int i) { if ((i & 2) && i < 16) st_pos((i >> 2) * 2 + (i & 1), 0); };
@@ -1072,7 +1158,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_qk(pB, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_qk(pA, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3) stage_w(ks_cur ^ 1, vs_next, k >> 2);
+                     if constexpr ((k & 3) == 3) {
+                         if constexpr (DMA) { if constexpr ((k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2); }
+                         else stage_w(ks_cur ^ 1, vs_next, k >> 2);
+                     }
 #endif
                  },
                  [&](int j) { read_v(vs_prev, j); });
@@ -1088,8 +1177,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      else valu_pv(nA_, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
                      if constexpr ((k & 3) == 3 && k < 32) {
-                         if constexpr ((k >> 2) < 4) stage_idx1(t + 2, k >> 2);
-                         stage_l(t + 2, k >> 2);
+                         if constexpr (DMA) {
+                             if constexpr ((k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2));
+                         } else {
+                             if constexpr ((k >> 2) < 4) stage_idx1(t + 2, k >> 2);
+                             stage_l(t + 2, k >> 2);
+                         }
                      }
                      if constexpr (k == 35) stage_ids(t + 3);
 #endif
@@ -1146,7 +1239,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         K1_STAMP(9);
         step_end();
     }
-    // a drain after the last step still reads the V ring, which the epilogue reuses for O
+    // a drain after the last step still reads the V ring, which the epilogue reuses for O (DMA:
+    // and the pieces requested past the last tile must have landed before O is written over them)
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef K1_ABL_NOBRANCH
     asm volatile("" ::"s"(abl_sticky));

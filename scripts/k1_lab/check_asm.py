@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Audit a K1 .s: no compiler-generated AGPR traffic outside inline-asm statements, no spills."""
+"""Audit a K1 .s: no compiler-generated AGPR traffic outside inline-asm statements, no spills,
+no VALU write of an MFMA operand right in front of an MFMA, M0 only inside the LDS-DMA statements."""
 import re, sys
 inasm = False
 bad = []
@@ -33,6 +34,22 @@ for k, (n, l) in enumerate(code):
         if pl.startswith('v_mfma') or not pl.startswith('v_'): continue
         dst = regs(pl.split(None, 1)[1].split(',')[0].strip())
         if dst & src: haz.append((n, pl, l))
+# M0 (the LDS-DMA destination) belongs to the DMA statements: the compiler must not use it, and
+# every DMA statement writes it itself right in front of its load
+m0bad, dmas = [], 0
+inasm = False
+for n, l in enumerate(lines, 1):
+    if ';;#ASMSTART' in l or '; ;#ASMSTART' in l: inasm = True
+    elif ';;#ASMEND' in l or '; ;#ASMEND' in l: inasm = False
+    elif re.search(r'\bm0\b', l) and not l.strip().startswith(';') and not inasm:
+        m0bad.append((n, l.strip()))
+for k, (n, l) in enumerate(code):
+    if re.search(r'buffer_load.* lds$', l):
+        dmas += 1
+        if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or code[k - 1][1] != 's_nop 0':
+            m0bad.append((n, l))
+print("LDS-DMA loads:", dmas, " M0 uses outside / malformed DMA statements:", len(m0bad))
+for n, l in m0bad[:6]: print(n, l)
 print("VALU write -> MFMA operand within 2 instructions:", len(haz))
 for h in haz[:6]: print(h)
 print("compiler uses of a[0:223] outside asm:", len(bad))
@@ -40,4 +57,4 @@ for n, l in bad[:10]: print(n, l)
 for key in ('.vgpr_spill_count', '.sgpr_spill_count', '.private_segment_fixed_size', '.vgpr_count', '.agpr_count', '.sgpr_count'):
     for line in open(sys.argv[1]):
         if key in line: print(line.strip())
-sys.exit(1 if (bad or haz) else 0)
+sys.exit(1 if (bad or haz or m0bad) else 0)
