@@ -311,15 +311,17 @@ constexpr int kGapBudget = 235;  // tenths of a cycle of fillers per gap
 enum DealMode { kDealSingle = 0, kDealDualA = 1, kDealDualB = 2 };
 // memory instructions a slice issues besides its MFMA: fragment reads of the next group (~4.5
 // cycles each), staging writes (ds_write_b128 ~13) / loads (~8)
+// staging = the LDS-DMA pieces in the first four staging positions of a slot
+constexpr int kDmaK = 180, kDmaV = 250;  // s_mov m0 + s_nop + buffer_load (+ index arithmetic, paged)
 constexpr int pv_mem_cost(int mode, int i) {
     if (i >= 16) return 0;
-    if (mode == kDealSingle) return (i & 3) < 2 ? 180 : 80;            // 4 tr reads | one buffer load
-    return ((i & 3) < 2 ? 90 : 0) + ((mode == kDealDualB && (i & 1)) ? 80 : 0);
+    if (mode == kDealSingle) return (i & 3) < 2 ? 180 : (i < 8 ? kDmaV : 0);
+    return ((i & 3) < 2 ? 90 : 0) + ((mode == kDealDualB && (i & 1) && i < 8) ? kDmaV : 0);
 }
 constexpr int qk_mem_cost(int mode, int i) {
     const bool last_group = i >= 12;                                   // prefetch of the first V^T fragments
-    if (mode == kDealSingle) return (i & 3) < 2 ? (last_group ? 180 : 90) : 130;
-    return ((i & 3) < 2 ? (last_group ? 90 : 45) : 0) + ((mode == kDealDualB && (i & 1)) ? 130 : 0);
+    if (mode == kDealSingle) return (i & 3) < 2 ? (last_group ? 180 : 90) : (i < 8 ? kDmaK : 0);
+    return ((i & 3) < 2 ? (last_group ? 90 : 45) : 0) + ((mode == kDealDualB && (i & 1) && i < 8) ? kDmaK : 0);
 }
 struct DealPlan {
     int cum[kPvSlices + kQkSlices + 2];  // units finished before P.V slice i / before QK^T slice i - 20
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
-    constexpr bool DMA = kDmaDense && !PAGED;
+    constexpr bool DMA = kDmaDense;
     constexpr int KTILE = DMA ? kKTileD : kKTile;
 
     const int tid = threadIdx.x;
@@ -584,21 +586,57 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
     unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
     u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};
+    // PAGED: a wave's four pieces of a tile are the 16 rows of ONE block of the sequence (block
+    // 4 tile + wave), so its id is a scalar (read through the scalar cache, three tiles ahead) and a
+    // lane's chunk index is id * chunks_per_block + a lane constant per piece; rows of V past the
+    // context get index -1 (true zeros), K needs no such care (those scores are masked)
+    unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
+    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // first chunk of the wave's block in tiles t+1, t+2, t+3
     if constexpr (DMA) {
         const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
-        dma_vv = rin * row_bytes + 16u * (pos ^ (4u * rin));
         const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
-        dma_krs = u32x4{(unsigned)ka, (unsigned)(ka >> 32) & 0xffffu, kv_bytes, 0x00020000u};
-        dma_vrs = u32x4{(unsigned)va, (unsigned)(va >> 32) & 0xffffu, kv_bytes, 0x00020000u};
+        if constexpr (PAGED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned r = 4u * j + rin;
+                dma_pk[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 16u + (pos ^ (r & 15u));
+                dma_pv[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 16u + (pos ^ (4u * rin));
+            }
+            dma_krs = u32x4{(unsigned)ka, ((unsigned)(ka >> 32) & 0xffffu) | (16u << 16), num_cache_chunks, 0x00020000u};
+            dma_vrs = u32x4{(unsigned)va, ((unsigned)(va >> 32) & 0xffffu) | (16u << 16), num_cache_chunks, 0x00020000u};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
+            dma_vv = rin * row_bytes + 16u * (pos ^ (4u * rin));
+            dma_krs = u32x4{(unsigned)ka, (unsigned)(ka >> 32) & 0xffffu, kv_bytes, 0x00020000u};
+            dma_vrs = u32x4{(unsigned)va, (unsigned)(va >> 32) & 0xffffu, kv_bytes, 0x00020000u};
+        }
     }
+    // PAGED: id of the block this wave fetches in key tile `tile` (clamped into the table row)
+    auto dma_id = [&](int tile) -> unsigned {
+        int bi = 4 * (tile + tile0) + wave;
+        bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
+        return (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi] * pg_chunks_per_block;
+    };
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
-    auto dma_piece = [&](int t, int kslot, int vslot, int j) {
+    auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u) {
         const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)(j & 3);
         const unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
         const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * KTILE) : (unsigned)(vslot * kVTile)) + r0 * 256u;
-        if (j < 4)
+        if constexpr (PAGED) {
+            const unsigned sbase = sid;  // block id * chunks per block (dma_id)
+            if (j < 4) {
+                const unsigned idx = sbase + dma_pk[j];
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 idxen lds"
+                             : : "s"(dst), "v"(idx), "s"(dma_krs) : "memory");
+            } else {
+                const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
+                const int r = 4 * (j & 3) + (lane >> 4);
+                const unsigned idx = r < rows_left ? sbase + dma_pv[j & 3] : 0xffffffffu;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 idxen lds"
+                             : : "s"(dst), "v"(idx), "s"(dma_vrs) : "memory");
+            }
+        } else if (j < 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          : : "s"(dst), "v"(dma_kv[j]), "s"(dma_krs), "s"(soff) : "memory");
         else
@@ -1002,12 +1040,19 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // trip before the first step instead of two of each.
     if constexpr (DMA) {
         // K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0; V slot 2 ("tile -1") zeroed
+        unsigned id0 = 0;
+        if constexpr (PAGED) {
+            id0 = dma_id(0);
+            pg_s0 = dma_id(1);
+            pg_s1 = dma_id(2);
+            pg_s2 = dma_id(3);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j);
+        for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j, id0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j);
+        for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j, pg_s0);
 #pragma unroll
-        for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j);
+        for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j, id0);
         commit_q(kA, qa);
         commit_q(kB, qb);
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -1074,15 +1119,20 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             ks_cur ^= 1;
         }
         ++t;
+        if constexpr (DMA && PAGED) {
+            pg_s0 = pg_s1;
+            pg_s1 = pg_s2;
+            pg_s2 = dma_id(t + 3);
+        }
     };
     // staging of a step, all at once (un-pipelined steps): tile t+1 (fetched during step t-1) goes
     // to LDS, then tile t+2 is fetched into the same registers
     auto stage_step = [&]() {
         if constexpr (DMA) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j);
+            for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j, pg_s1);
 #pragma unroll
-            for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j);
+            for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j, pg_s0);
         } else {
             stage_write(ks_cur ^ 1, vs_next);
             stage_load(t + 2);
@@ -1104,8 +1154,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto st_pos = [&](int p, int base) {
         if constexpr (DMA) {  // K pieces of tile t+2 in the QK^T slot, V pieces of tile t+1 in the P.V slot
             if (p < 4) {
-                if (base == 0) dma_piece(t + 2, ks_n2, 0, p);
-                else dma_piece(t + 1, 0, vs_next, 4 + p);
+                if (base == 0) dma_piece(t + 2, ks_n2, 0, p, pg_s1);
+                else dma_piece(t + 1, 0, vs_next, 4 + p, pg_s0);
             }
         } else {
             if (p & 1) stage_l(t + 2, base + (p >> 1));
@@ -1124,7 +1174,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // multiplied.  MASKED (A's last tile): the fresh scores are masked between the two slots, the
     // rest of the step is the same, and the caller drains `nxt` afterwards.
     auto single_step = [&](Item &cur, Item &nxt, auto masked) {
-        stage_next(t + 2);
+        if constexpr (!DMA) stage_next(t + 2);
         prime_k();
         slot_qk(nxt, kA, ks_cur, cur,
                 [&](auto I) {
@@ -1159,7 +1209,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      else valu_qk(pA, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
                      if constexpr ((k & 3) == 3) {
-                         if constexpr (DMA) { if constexpr ((k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2); }
+                         if constexpr (DMA) { if constexpr ((k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2, pg_s1); }
                          else stage_w(ks_cur ^ 1, vs_next, k >> 2);
                      }
 #endif
@@ -1178,13 +1228,13 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifndef K1_ABL_NOSTAGE
                      if constexpr ((k & 3) == 3 && k < 32) {
                          if constexpr (DMA) {
-                             if constexpr ((k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2));
+                             if constexpr ((k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2), pg_s0);
                          } else {
                              if constexpr ((k >> 2) < 4) stage_idx1(t + 2, k >> 2);
                              stage_l(t + 2, k >> 2);
                          }
                      }
-                     if constexpr (k == 35) stage_ids(t + 3);
+                     if constexpr (k == 35 && !DMA) stage_ids(t + 3);
 #endif
                  },
                  no_rd);
