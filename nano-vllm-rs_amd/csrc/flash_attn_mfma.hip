@@ -45,12 +45,6 @@
 
 #include "nvllm_kernels.hpp"
 
-typedef __attribute__((ext_vector_type(4))) int nvllm_i32x4;
-// indexed ("idxen") buffer load: address = base + index * stride; hipcc has no builtin for it
-__device__ nvllm_i32x4 nvllm_struct_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, int vindex,
-                                                     int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.struct.ptr.buffer.load.v4i32");
-
 namespace nvllm {
 namespace kernels {
 
@@ -68,22 +62,15 @@ constexpr int kD = 128;
 constexpr int kWaves = 4;
 constexpr int kQTile = 32 * kWaves;  // query rows per tile (two tiles per workgroup)
 constexpr int kKV = 64;              // keys per tile
-constexpr int kVRow = 256, kVTile = kKV * kVRow;  // 16 KiB, swizzled
-constexpr int kKRow = 272, kKTile = kKV * kKRow;  // 17 KiB, padded rows (conflict-free b128 reads)
-constexpr int kVRing = 3, kKRing = 2;
+constexpr int kVRow = 256, kVTile = kKV * kVRow;  // 16 KiB, chunks XOR-swizzled by the row
+constexpr int kKRow = 256, kKTile = kKV * kKRow;  // 16 KiB, likewise (conflict-free b128 row reads)
+// K/V tiles go HBM -> LDS directly (buffer_load ... lds, no staging registers, no ds_write): an
+// instruction writes 1 KiB linearly, so both images have plain 256-byte rows and the swizzle is
+// applied through each lane's SOURCE address.  K ring of 3: a tile is requested two steps before
+// it is read; V ring of 3: one step before, and read a step later than K.
+constexpr int kVRing = 3, kKRing = 3;
 constexpr int kKBase = kVRing * kVTile;
-// Dense launches: K/V tiles go HBM -> LDS directly (buffer_load ... lds, no staging
-// registers, no ds_write): an instruction writes 1 KiB linearly, so the K image has plain 256-byte
-// rows with the chunks XOR-swizzled by the row (through each lane's SOURCE address), and a third
-// slot so that a tile can be requested two steps before it is read.
-#ifdef K1_NO_DMA  // lab only: the register-staged path for A/B runs
-constexpr bool kDmaDense = false;
-#else
-constexpr bool kDmaDense = true;
-#endif
-constexpr int kKRowD = 256, kKTileD = kKV * kKRowD, kKRingD = 3;
-constexpr int kLdsBytes =
-    kKBase + (kDmaDense && kKRingD * kKTileD > kKRing * kKTile ? kKRingD * kKTileD : kKRing * kKTile);
+constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 98,304 B
 constexpr int kORow = 272, kOStage = 32 * kORow;  // epilogue: O rows of a block, padded
 static_assert(2 * kWaves * kOStage <= kLdsBytes, "O staging must fit the K/V rings");
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
@@ -394,8 +381,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
-    constexpr bool DMA = kDmaDense;
-    constexpr int KTILE = DMA ? kKTileD : kKTile;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -553,35 +538,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // over this (batch, kv head)'s rows: the tile offset rides in the scalar offset (no address
     // arithmetic per load) and rows past Skv read as zero (those keys are masked out of S in the
     // block's last tile, so their P is exactly 0).
-    const int st_ch = tid & 15;
-    const int st_row0 = tid >> 4;
     const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
     const unsigned kv_bytes = PAGED ? 0u : (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
     const int64_t head_off = PAGED ? 0 : ((int64_t)b * Skv * Hkv + kvh) * kD;
     // PAGED: the caches are addressed as arrays of 16-byte chunks (stride 16, indexed loads): a
-    // 32-bit chunk index reaches 64 GiB, and an index past the cache reads as zero like above.
-    // Piece i of key tile t is the 16 rows of the sequence's block 4t + i, whose id comes from the
-    // block table (a raw buffer over this sequence's row: entries past it read as id 0).  Rows
-    // past the context (never written, or stale) are given the index -1: their V must be a true
-    // zero, P = 0 would not silence a NaN.
-    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(k + head_off), PAGED ? 16 : 0, PAGED ? (int)num_cache_chunks : (int)kv_bytes,
-        0x00020000);
-    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16 *>(v + head_off), PAGED ? 16 : 0, PAGED ? (int)num_cache_chunks : (int)kv_bytes,
-        0x00020000);
-    const auto tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int32_t *>(PAGED ? block_tables + (int64_t)b * max_blocks_per_seq : nullptr), 0,
-        PAGED ? max_blocks_per_seq * 4 : 0, 0x00020000);
+    // 32-bit chunk index reaches 64 GiB, and an index past the cache reads as zero like a row past
+    // Skv of a dense launch.
     const unsigned pg_chunks_per_block = (unsigned)(16 * Hkv * 16);
-    const unsigned pg_chunk0 = (unsigned)((st_row0 * Hkv + kvh) * 16 + st_ch);
-    const int pg_blk_lim = (Skv - st_row0 + 15) >> 4;  // blocks holding a row st_row0 below Skv
-    const unsigned st_voff = (unsigned)st_row0 * row_bytes + 16u * (unsigned)st_ch;
-    const unsigned st_kw = (unsigned)(kKBase + st_row0 * kKRow + 16 * st_ch);
-    const unsigned st_vw = (unsigned)(st_row0 * kVRow + 16 * (st_ch ^ (4 * (st_row0 & 3))));
-    u32x4 st[8];
-    unsigned pg_id[4], pg_idx[4];
-    // DMA: piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
+    // Piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
     // instruction: lane L writes LDS bytes [16 L, 16 L + 16) of the piece's 1 KiB, i.e. position
     // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
     unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
@@ -592,7 +556,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // context get index -1 (true zeros), K needs no such care (those scores are masked)
     unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
     unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // first chunk of the wave's block in tiles t+1, t+2, t+3
-    if constexpr (DMA) {
+    {
         const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
         const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
         if constexpr (PAGED) {
@@ -622,7 +586,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u) {
         const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)(j & 3);
         const unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
-        const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * KTILE) : (unsigned)(vslot * kVTile)) + r0 * 256u;
+        const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + r0 * 256u;
         if constexpr (PAGED) {
             const unsigned sbase = sid;  // block id * chunks per block (dma_id)
             if (j < 4) {
@@ -643,69 +607,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          : : "s"(dst), "v"(dma_vv), "s"(dma_vrs), "s"(soff) : "memory");
     };
-    // PAGED: fetch the four block ids of key tile t; stage_idx(t) turns them into this thread's
-    // chunk indices a step later (the table read then has a whole step to land), stage_l uses those
-    auto stage_ids_to = [&](unsigned (&dst)[4], int t) {
-        if constexpr (PAGED) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                dst[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, 4 * i, 16 * (t + tile0), 0);
-        }
-    };
-    auto stage_ids = [&](int t) { stage_ids_to(pg_id, t); };
-    auto stage_idx1 = [&](int t, int j) {
-        if constexpr (PAGED) {
-            unsigned idx;  // hipcc turns __umul24 into and + v_mul_lo_u32 (quarter rate)
-            asm("v_mad_u32_u24 %0, %1, %2, %3"
-                : "=v"(idx) : "v"(pg_id[j]), "s"(pg_chunks_per_block), "v"(pg_chunk0));
-            pg_idx[j] = (4 * (t + tile0) + j >= pg_blk_lim) ? 0xffffffffu : idx;
-        }
-    };
-    auto stage_idx = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) stage_idx1(t, j);
-    };
-    // the ids in hand become tile t's indices, tile t+1's ids are requested
-    auto stage_next = [&](int t) {
-        stage_idx(t);
-        stage_ids(t + 1);
-    };
-    // fetch piece j of key tile t (PAGED: of the tile stage_idx was last called for)
-    auto stage_l_to = [&](u32x4 (&dst)[8], int t, int j) {
-        if constexpr (PAGED) {
-            dst[j] = __builtin_bit_cast(u32x4, nvllm_struct_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc,
-                                                                       (int)pg_idx[j & 3], 0, 0, 0));
-        } else {
-            const unsigned soff = ((unsigned)t * kKV + 16u * (unsigned)(j & 3)) * row_bytes;
-            dst[j] = __builtin_bit_cast(
-                u32x4, __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? k_rsrc : v_rsrc, st_voff, soff, 0));
-        }
-    };
-    auto stage_l = [&](int t, int j) { stage_l_to(st, t, j); };
-    // write piece j to K ring slot kslot / V ring slot vslot
-    auto stage_w_from = [&](const u32x4 (&src)[8], int kslot, int vslot, int j) {
-        if (j < 4)
-            *reinterpret_cast<u32x4 *>(lds + st_kw + kslot * kKTile + j * 16 * kKRow) = src[j];
-        else
-            *reinterpret_cast<u32x4 *>(lds + st_vw + vslot * kVTile + (j - 4) * 16 * kVRow) = src[j];
-    };
-    auto stage_w = [&](int kslot, int vslot, int j) { stage_w_from(st, kslot, vslot, j); };
-    auto stage_load = [&](int t) {
-        stage_next(t);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_l(t, j);
-    };
-    auto stage_write = [&](int kslot, int vslot) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_w(kslot, vslot, j);
-    };
 
     // ---- LDS read addresses
-    // K A-fragment (u, ks): row 32u + c, 16-byte chunk 2ks + h of a padded row
-    const unsigned k_rd = (unsigned)(kKBase + c * kKRow + 16 * h);
-    unsigned k_rd8[8];  // DMA image: chunk 2ks + h of row c (mod 16) sits at position (2ks + h) ^ (c & 15)
+    // K A-fragment (u, ks): row 32u + c, 16-byte chunk 2ks + h, which sits at position (2ks + h) ^ (c & 15)
+    unsigned k_rd8[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) k_rd8[ks] = (unsigned)(kKBase + c * kKRowD + 16 * ((2 * ks + h) ^ (c & 15)));
+    for (int ks = 0; ks < 8; ++ks) k_rd8[ks] = (unsigned)(kKBase + c * kKRow + 16 * ((2 * ks + h) ^ (c & 15)));
     // V^T A-fragment (transposed read): 16-lane group g16 = lane>>4 covers d chunk
     // 4dt + 2(g16&1) + (p>>1), key rows 16sp + 4h + qq (+8 for the second read)
     const int c16 = lane & 15, qq = c16 >> 2, pp = c16 & 3, g16 = lane >> 4;
@@ -722,12 +629,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     u32x4 fr[8];
     // K fragment i (u = i>>3, ks = i&7) of a QK slot
     auto read_k = [&](int slot, int i) {
-        if constexpr (DMA) {
-            fr[i & 7] = *reinterpret_cast<const u32x4 *>(lds + k_rd8[i & 7] + slot * KTILE + (i >> 3) * 32 * kKRowD);
-        } else {
-            const unsigned char *kt = lds + k_rd + slot * kKTile;
-            fr[i & 7] = *reinterpret_cast<const u32x4 *>(kt + (i >> 3) * 32 * kKRow + 32 * (i & 7));
-        }
+        fr[i & 7] = *reinterpret_cast<const u32x4 *>(lds + k_rd8[i & 7] + slot * kKTile + (i >> 3) * 32 * kKRow);
     };
     // V^T fragment i (dt = i>>2, sp = i&3) of a PV slot
     auto read_v = [&](int slot, int i) {
@@ -1034,12 +936,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         it.mx = -INFINITY;
         it.xf = -INFINITY; it.ya = 0.0f; it.yb = 0.0f;
     };
-    // ---- prologue: tile 0 into slot 0, V slot 2 ("tile -1") zeroed, tile 1 in flight.  Tiles 0 and
-    // 1 are requested together (tile 0 into registers of its own, which only live here, where
-    // nothing else does yet), and so are their block ids: one table round trip and one K/V round
-    // trip before the first step instead of two of each.
-    if constexpr (DMA) {
-        // K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0; V slot 2 ("tile -1") zeroed
+    // ---- prologue: K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0, all requested together (and,
+    // PAGED, the ids of the wave's blocks in tiles 0..3); V slot 2 ("tile -1") zeroed
+    {
         unsigned id0 = 0;
         if constexpr (PAGED) {
             id0 = dma_id(0);
@@ -1060,27 +959,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        u32x4 st0[8];
-        unsigned pg_id1[4] = {0u, 0u, 0u, 0u};
-        stage_ids(0);
-        stage_ids_to(pg_id1, 1);
-        stage_idx(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_l_to(st0, 0, j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pg_id[i] = pg_id1[i];
-        stage_next(1);  // tile 1's indices, tile 2's ids
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_l(1, j);
-        commit_q(kA, qa);
-        commit_q(kB, qb);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage_w_from(st0, 0, 0, j);
     }
     __syncthreads();
     clear_item(I0);
@@ -1090,7 +968,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 
     int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
     int ks_cur = 0;                            // K ring slot of tile t
-    int ks_n1 = 1, ks_n2 = 2;                  // DMA: K ring slots of tiles t+1, t+2
+    int ks_n1 = 1, ks_n2 = 2;                  // K ring slots of tiles t+1, t+2
     K1_STAMP(2);  // kernel start .. first step (Q load, first two tiles)
     // Every wave runs the same number of steps (nsteps), one barrier each, but walks them in its
     // own phases -- separate loops, so that each hot loop is one straight body whose registers
@@ -1098,9 +976,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     int t = 0;
     // end of a step: publish tile t+1 (written during this step), rotate the rings
     auto step_end = [&]() {
-        // DMA: the wave's 8 pieces of this step (K of tile t+2, V of tile t+1) may stay in flight,
-        // the 8 of the step before (K of t+1, V of t: read in the next step) must have landed
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the wave's 8 pieces of this step (K of tile t+2, V of tile t+1) may stay in flight, the 8
+        // of the step before (K of t+1, V of t: read in the next step) must have landed; hipcc does
+        // not count LDS-DMA issued from asm, so __syncthreads() below is a bare s_barrier
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
         K1_STAMP(11);  // barrier
 #ifdef NVLLM_K1_STAMPS
@@ -1110,56 +989,34 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         vs_prev = vs_cur;
         vs_cur = vs_next;
         vs_next = x;
-        if constexpr (DMA) {
-            const int y = ks_cur;
-            ks_cur = ks_n1;
-            ks_n1 = ks_n2;
-            ks_n2 = y;
-        } else {
-            ks_cur ^= 1;
-        }
+        const int y = ks_cur;
+        ks_cur = ks_n1;
+        ks_n1 = ks_n2;
+        ks_n2 = y;
         ++t;
-        if constexpr (DMA && PAGED) {
+        if constexpr (PAGED) {
             pg_s0 = pg_s1;
             pg_s1 = pg_s2;
             pg_s2 = dma_id(t + 3);
         }
     };
-    // staging of a step, all at once (un-pipelined steps): tile t+1 (fetched during step t-1) goes
-    // to LDS, then tile t+2 is fetched into the same registers
+    // staging of a step, all at once (steps this wave has no keys for): K of tile t+2, V of tile t+1
     auto stage_step = [&]() {
-        if constexpr (DMA) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j, pg_s1);
+        for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j, pg_s1);
 #pragma unroll
-            for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j, pg_s0);
-        } else {
-            stage_write(ks_cur ^ 1, vs_next);
-            stage_load(t + 2);
-        }
+        for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j, pg_s0);
     };
     // ... or dealt out over the MFMA gaps of the pipelined bodies, into slices that issue no
-    // fragment reads.  Either way a step starts with tile t+1 in the staging registers (landed or
-    // in flight) and tile t+2's block ids in pg_id, and ends one tile further.
-    // Two-block steps: the eight writes in the QK^T slot, the eight fetches in the P.V slot, so the
-    // registers are free in between (the step's register peak) and a fetch has one slot, about 1700
-    // cycles, to land.  One-block steps are half as long and have registers to spare: position
-    // p = 0..7 of a slot writes (p even) piece p/2 to LDS or refills (p odd) the same registers with
-    // that piece of tile t+2 -- K pieces in the QK^T slot, V pieces in the P.V slot -- so a fetch
-    // has the whole step to land (with one slot, about 950 cycles, HBM-streaming launches waited
-    // in every step: 2735 cycles a step against 1960 from L2).
+    // fragment reads: the K pieces in the first four staging positions of the QK^T slot, the V
+    // pieces in the first four of the P.V slot
 #ifdef K1_ABL_NOSTAGE
     auto st_pos = [&](int, int) {};
 #else
     auto st_pos = [&](int p, int base) {
-        if constexpr (DMA) {  // K pieces of tile t+2 in the QK^T slot, V pieces of tile t+1 in the P.V slot
-            if (p < 4) {
-                if (base == 0) dma_piece(t + 2, ks_n2, 0, p, pg_s1);
-                else dma_piece(t + 1, 0, vs_next, 4 + p, pg_s0);
-            }
-        } else {
-            if (p & 1) stage_l(t + 2, base + (p >> 1));
-            else stage_w(ks_cur ^ 1, vs_next, base + (p >> 1));
+        if (p < 4) {
+            if (base == 0) dma_piece(t + 2, ks_n2, 0, p, pg_s1);
+            else dma_piece(t + 1, 0, vs_next, 4 + p, pg_s0);
         }
     };
 #endif
@@ -1174,7 +1031,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // multiplied.  MASKED (A's last tile): the fresh scores are masked between the two slots, the
     // rest of the step is the same, and the caller drains `nxt` afterwards.
     auto single_step = [&](Item &cur, Item &nxt, auto masked) {
-        if constexpr (!DMA) stage_next(t + 2);
         prime_k();
         slot_qk(nxt, kA, ks_cur, cur,
                 [&](auto I) {
@@ -1208,10 +1064,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_qk(pB, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_qk(pA, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3) {
-                         if constexpr (DMA) { if constexpr ((k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2, pg_s1); }
-                         else stage_w(ks_cur ^ 1, vs_next, k >> 2);
-                     }
+                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2, pg_s1);
 #endif
                  },
                  [&](int j) { read_v(vs_prev, j); });
@@ -1226,15 +1079,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_pv(nB_, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_pv(nA_, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3 && k < 32) {
-                         if constexpr (DMA) {
-                             if constexpr ((k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2), pg_s0);
-                         } else {
-                             if constexpr ((k >> 2) < 4) stage_idx1(t + 2, k >> 2);
-                             stage_l(t + 2, k >> 2);
-                         }
-                     }
-                     if constexpr (k == 35 && !DMA) stage_ids(t + 3);
+                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2), pg_s0);
 #endif
                  },
                  no_rd);
@@ -1289,9 +1134,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         K1_STAMP(9);
         step_end();
     }
-    // a drain after the last step still reads the V ring, which the epilogue reuses for O (DMA:
-    // and the pieces requested past the last tile must have landed before O is written over them)
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // a drain after the last step still reads the V ring, which the epilogue reuses for O, and the
+    // pieces requested past the last tile must have landed before O is written over them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef K1_ABL_NOBRANCH
     asm volatile("" ::"s"(abl_sticky));

@@ -1,3 +1,4 @@
+# K1-focused GPU tests, then the lab (paged and dense shapes)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
