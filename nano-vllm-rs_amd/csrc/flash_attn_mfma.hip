@@ -1114,11 +1114,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // happens when a key split cuts the walks; with no block B both sets are empty anyway)
     if (t < nA) {
         const int n2 = nA - 1 - t;
-        if (!(n2 & 1) && nB > 0) {
-            const Item x = I0;
-            I0 = I1;
-            I1 = x;
-        }
+        if (!(n2 & 1) && nB > 0) I0 = I1;  // set 0's old content is dead: its P.V is done
         if (n2 & 1) single_step(I1, I0, kInterior);
         while (t < nA - 1) {
             single_step(I0, I1, kInterior);
