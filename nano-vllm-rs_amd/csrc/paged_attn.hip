@@ -387,6 +387,34 @@ __global__ __launch_bounds__(64 * HPB) void paged_attn_kernel(
     // ---- main loop: register double buffering, ids two tiles ahead; tiles [t0, t1)
     auto run_tiles = [&](auto stream_tag, int t0, int t1) {
         if (t0 >= t1) return;
+        if constexpr (NQT == 2) {
+            // two query tiles run one wave per SIMD (512 registers): four waves per CU instead of
+            // eight, so each keeps TWO tiles in flight (three register sets) to have the same
+            // 128 KiB per CU on their way
+            TileRegs ta, tb, tc;
+            int a0, a1, b0, b1, c0, c1;  // ids of the tiles that go into ta / tb / tc next
+            load_ids(t0, a0, a1);
+            load_ids(t0 + 1, b0, b1);
+            load_ids(t0 + 2, c0, c1);
+            load_tile(stream_tag, ta, a0, a1);
+            if (t0 + 1 < t1) load_tile(stream_tag, tb, b0, b1);
+            load_ids(t0 + 3, a0, a1);
+            load_ids(t0 + 4, b0, b1);
+            for (int t = t0; t < t1; t += 3) {
+                if (t + 2 < t1) load_tile(stream_tag, tc, c0, c1);
+                load_ids(t + 5, c0, c1);
+                compute_tile(ta, t);
+                if (t + 1 >= t1) break;
+                if (t + 3 < t1) load_tile(stream_tag, ta, a0, a1);
+                load_ids(t + 6, a0, a1);
+                compute_tile(tb, t + 1);
+                if (t + 2 >= t1) break;
+                if (t + 4 < t1) load_tile(stream_tag, tb, b0, b1);
+                load_ids(t + 7, b0, b1);
+                compute_tile(tc, t + 2);
+            }
+            return;
+        }
         TileRegs ta, tb;
         int a0, a1, n0, n1;
         load_ids(t0, a0, a1);
