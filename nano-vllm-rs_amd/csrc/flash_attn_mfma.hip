@@ -28,11 +28,11 @@
 //     softmax of item k.  While both blocks have keys left the items alternate
 //     A,B on the same key tile; after that block A alternates over two score
 //     register sets.  Only a block's LAST key tile needs a mask (diagonal or
-//     ragged tail); it runs un-pipelined.
-//   * K/V tiles of 64 keys are shared by the 4 waves through LDS rings (K x2
-//     with rows padded to 272 B, V x3 XOR-swizzled for ds_read_b64_tr_b16),
-//     fetched HBM -> VGPR a whole step ahead and written to LDS at the start
-//     of the next step; one barrier per key tile.
+//     ragged tail): a pipelined step like the others, masked between its slots.
+//   * K/V tiles of 64 keys are shared by the 4 waves through LDS rings (K x3,
+//     V x3; 256-byte rows, chunks XOR-swizzled by the row), filled HBM -> LDS
+//     directly by buffer_load ... lds one (V) or two (K) steps ahead; one
+//     barrier per key tile behind a counted s_waitcnt vmcnt.
 //   * blockIdx.x enumerates kv head fastest so that the workgroups sharing a
 //     kv head's K/V stream land on one XCD's L2 when Hkv is a multiple of 8.
 #include <hip/hip_runtime.h>
