@@ -427,6 +427,19 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
     // the tiling starts) and the dead rows in front of the first block (pos_shift)
     int kv_off = 0, pos_base = 0, pos_shift = 0;
+    // PAGED, no key split: the ids of the wave's blocks in key tiles 0..3 depend on nothing but the
+    // sequence, so they are requested here, beside the context length, not behind it (one scalar
+    // cache miss less in the prologue's chain length -> ids -> tiles)
+    unsigned early_id[4] = {0u, 0u, 0u, 0u};
+    if constexpr (PAGED && !KSPLIT) {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int bi = 4 * i + w;
+            bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
+            early_id[i] = (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
+        }
+    }
     if constexpr (PAGED) {
         Skv = context_lens[b];
         const int cap = max_blocks_per_seq * 16;
@@ -940,7 +953,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // PAGED, the ids of the wave's blocks in tiles 0..3); V slot 2 ("tile -1") zeroed
     {
         unsigned id0 = 0;
-        if constexpr (PAGED) {
+        if constexpr (PAGED && !KSPLIT) {
+            id0 = early_id[0] * pg_chunks_per_block;
+            pg_s0 = early_id[1] * pg_chunks_per_block;
+            pg_s1 = early_id[2] * pg_chunks_per_block;
+            pg_s2 = early_id[3] * pg_chunks_per_block;
+        } else if constexpr (PAGED) {
             id0 = dma_id(0);
             pg_s0 = dma_id(1);
             pg_s1 = dma_id(2);
