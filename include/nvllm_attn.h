@@ -103,8 +103,9 @@ int nvllm_flash_attn_fwd_f32(const void *q, const void *k, const void *v, void *
  * <= 16 always runs the bandwidth kernel (decode, short verify), up to 48 when
  * the launch is large or the contexts long; more query rows
  * (chunked prefill, long verify) run the prefill kernel reading K/V through the
- * block table (needs a cache of < 64 GiB and < 2^24 blocks); other shapes run
- * the generic kernel. */
+ * block table (any cache size: a block is addressed through its own 64-bit
+ * base); other shapes run the generic kernel.  nvllm_paged_attn_path() says
+ * which of the three a launch shape takes. */
 int nvllm_paged_attn_bf16(const void *q, const void *k_cache, const void *v_cache,
                           const int32_t *block_tables, const int32_t *context_lens, void *out,
                           void *workspace, size_t workspace_bytes, int num_seqs,
@@ -128,7 +129,10 @@ int nvllm_paged_attn_f32(const void *q, const void *k_cache, const void *v_cache
  * is refused with NVLLM_ERR_UNSUPPORTED (nothing is launched); shapes that need no workspace
  * never touch the scratch.  The call allocates and frees nothing and does not synchronise.  All
  * calls on one GPU share that GPU's array: two calls that overlap in time on one GPU (different
- * streams, or threads) race on it -- serialise them or use the workspace form. */
+ * streams, or threads) race on it -- serialise them or use the workspace form.  The array's
+ * address on a device is looked up once per device: by nvllm_set_device(), else by the first call
+ * on that device -- which is then not a pure stream operation, so under stream capture call
+ * nvllm_set_device() (or make one call) on the device beforehand. */
 int nvllm_paged_attn_bf16_noalloc(const void *q, const void *k_cache, const void *v_cache,
                                   const int32_t *block_tables, const int32_t *context_lens, void *out,
                                   int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
@@ -137,14 +141,29 @@ int nvllm_paged_attn_bf16_noalloc(const void *q, const void *k_cache, const void
 size_t nvllm_paged_attn_noalloc_max_scratch_bytes(void);
 
 /* Bytes of split-K scratch nvllm_paged_attn_* needs for this launch shape
- * (an upper bound over all context lengths <= max_blocks_per_seq*block_size).
+ * (an upper bound over all context lengths <= max_blocks_per_seq*block_size and
+ * over what the shape does not say: a launch that ends in the generic kernel --
+ * misaligned tensors, NVLLM_PAGED_FLASH=0 -- needs none and accepts none).
  * The launch takes its split decision from the same arguments by the same
- * arithmetic; a workspace smaller than this value (or NULL when it is > 0, or
- * not 16-byte aligned) is rejected with NVLLM_ERR_CONFIG -- never a silently
- * different launch. */
+ * arithmetic; a workspace smaller than what the launch needs (or NULL when that
+ * is > 0, or not 16-byte aligned) is rejected with NVLLM_ERR_CONFIG -- never a
+ * silently different launch.  The split factors follow the compute-unit count of
+ * the CURRENT device: make the query with the launch device current. */
 size_t nvllm_paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,
                                         int num_kv_heads, int head_dim, int block_size,
                                         int max_blocks_per_seq);
+
+/* Which kernel nvllm_paged_attn_* runs for a launch shape (a pure query: nothing is launched, no
+ * pointer is looked at -- 16-byte aligned tensors are assumed).  No counterpart in the reference
+ * (paged.rs:117-192 has one path); it exists so that callers and tests can see that a verify or
+ * prefill chunk (src/speculative/engine.rs:146-169) is NOT on the scalar generic kernel.
+ *   0 = decode kernel (bandwidth, MFMA 16x16x32, split-K)      csrc/paged_attn.hip
+ *   1 = prefill kernel over the cache (MFMA 32x32x16, K1 paged) csrc/flash_attn_mfma.hip
+ *   2 = generic kernel (any head_dim / block_size / f32)
+ * dtype 0 bf16, 1 f32.  Negative nvllm_status on invalid dimensions. */
+int nvllm_paged_attn_path(int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
+                          int head_dim, int block_size, int max_blocks_per_seq,
+                          int64_t num_cache_blocks, int dtype);
 
 /* KV write ("reshape_and_cache"): for each token p,
  *   cache[slot/bs, slot%bs, :, :] = key[p, :, :]   (and value),  slot = slot_mapping[p].
@@ -246,7 +265,8 @@ int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64
 int nvllm_debug_set_policy(const char *name, int value);
 void nvllm_debug_reset_policy(void);
 
-/* Device inventory used by the sharded launcher and the bench. */
+/* Device inventory used by the sharded launcher and the bench.  nvllm_set_device also resolves
+ * the no-allocation entry's scratch address on that device. */
 int nvllm_device_count(void);
 int nvllm_set_device(int device);
 

@@ -118,6 +118,19 @@ def paged_attention(query, kv_cache, block_table, context_len, num_heads, num_kv
     return out
 
 
+PAGED_PATHS = ("decode", "k1_paged", "generic")
+
+
+def paged_attention_path(num_seqs, num_new_tokens, num_heads, num_kv_heads, head_dim, block_size,
+                         max_blocks_per_seq, num_cache_blocks, dtype=torch.bfloat16):
+    """nvllm_paged_attn_path: which kernel a batched launch of this shape runs (pure query)."""
+    code = capi.lib().nvllm_paged_attn_path(num_seqs, num_new_tokens, num_heads, num_kv_heads, head_dim,
+                                            block_size, max_blocks_per_seq, num_cache_blocks,
+                                            0 if dtype == torch.bfloat16 else 1)
+    check(min(code, 0))
+    return PAGED_PATHS[code]
+
+
 def paged_attention_batched(query, key_cache, value_cache, block_tables, context_lens, scale,
                             workspace=None):
     """Batched form (nvllm_paged_attn_*): query [num_seqs,T,Hq,D], block_tables int32

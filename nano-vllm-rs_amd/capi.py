@@ -33,6 +33,7 @@ SIGNATURES = {
     "nvllm_paged_attn_bf16_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _f, _vp]),
     "nvllm_paged_attn_noalloc_max_scratch_bytes": (_sz, []),
     "nvllm_paged_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "nvllm_paged_attn_path": (_i, [_i, _i, _i, _i, _i, _i, _i, _i64, _i]),
     "nvllm_reshape_and_cache_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),
     "nvllm_reshape_and_cache_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i64, _vp]),
     "nvllm_qk_norm_rope_cache_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i64, _vp]),

@@ -101,11 +101,8 @@ int paged_common(kernels::DType dt, const void *q, const void *k_cache, const vo
     // the split decision is a function of the launch shape (and the launch policy) alone, and
     // nvllm_paged_attn_workspace_bytes is that same function: a smaller workspace is a caller
     // error, not a reason to launch differently
-    const size_t need = dt == kernels::DType::BF16
-                            ? kernels::paged_attn_workspace_bytes(num_seqs, num_new_tokens, num_heads,
-                                                                  num_kv_heads, head_dim, block_size,
-                                                                  max_blocks_per_seq)
-                            : 0;
+    // (what this launch needs: the shape's figure, or 0 when the generic kernel runs)
+    const size_t need = kernels::paged_attn_launch_workspace_bytes(dt, a);
     if (noalloc) {
         if (need > kernels::kNoAllocScratchBytes)
             return fail(ErrorKind::Unsupported,
@@ -305,7 +302,33 @@ int nvllm_device_count(void) {
     return n;
 }
 
-int nvllm_set_device(int device) { return hip_status(hipSetDevice(device), "set_device"); }
+int nvllm_set_device(int device) {
+    const int rc = hip_status(hipSetDevice(device), "set_device");
+    if (rc != NVLLM_OK) return rc;
+    // the no-allocation entry's scratch address on this device, looked up here so that its launch
+    // path never does (a symbol lookup is not a stream operation: not for a capturing stream)
+    return hip_status(kernels::noalloc_prepare_device(), "set_device: scratch address");
+}
+
+int nvllm_paged_attn_path(int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
+                          int head_dim, int block_size, int max_blocks_per_seq,
+                          int64_t num_cache_blocks, int dtype) {
+    if (num_seqs <= 0 || num_new_tokens <= 0 || num_heads <= 0 || num_kv_heads <= 0 || head_dim <= 0 ||
+        block_size <= 0 || max_blocks_per_seq <= 0 || num_cache_blocks <= 0 || (dtype != 0 && dtype != 1))
+        return fail(ErrorKind::Config, "paged_attn_path: negative or zero dimension, or unknown dtype");
+    if (num_heads % num_kv_heads != 0)
+        return fail(ErrorKind::Config, "paged_attn_path: num_heads must be a multiple of num_kv_heads");
+    kernels::PagedAttnArgs a{};
+    a.num_seqs = num_seqs;
+    a.num_new_tokens = num_new_tokens;
+    a.num_heads = num_heads;
+    a.num_kv_heads = num_kv_heads;
+    a.head_dim = head_dim;
+    a.block_size = block_size;
+    a.max_blocks_per_seq = max_blocks_per_seq;
+    a.num_cache_blocks = num_cache_blocks;
+    return (int)kernels::paged_attn_path(dtype == 0 ? kernels::DType::BF16 : kernels::DType::F32, a);
+}
 
 /* ---- host logic --------------------------------------------------------- */
 

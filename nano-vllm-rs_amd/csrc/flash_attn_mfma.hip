@@ -45,6 +45,15 @@
 
 #include "nvllm_kernels.hpp"
 
+// The lab switches below (scripts/k1_lab: cycle stamps, ablations that produce WRONG results by
+// design) must never reach the product library: they compile only when the lab says who it is.
+#if !defined(NVLLM_K1_LAB) &&                                                                      \
+    (defined(NVLLM_K1_STAMPS) || defined(K1_FINE) || defined(K1_RT) || defined(K1_ABL_NOVALU) ||   \
+     defined(K1_ABL_NOSTAGE) || defined(K1_ABL_NOBRANCH) || defined(K1_ABL_SKIP_KINDS) ||          \
+     defined(K1_DBG_VALU_L) || defined(K1_DBG_FENCE))
+#error "K1 lab switch (NVLLM_K1_STAMPS / K1_ABL_* / K1_DBG_*) defined without NVLLM_K1_LAB: not a product build"
+#endif
+
 namespace nvllm {
 namespace kernels {
 
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv, int Hq, int Hkv,
     int num_q_tiles, int pair_adjacent, float scale_log2e,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
-    int max_blocks_per_seq, unsigned num_cache_chunks, unsigned char *__restrict__ split_ws,
+    int max_blocks_per_seq, unsigned num_cache_blocks, unsigned char *__restrict__ split_ws,
     int pack_shift, int num_seqs) {
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
@@ -554,10 +563,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
     const unsigned kv_bytes = PAGED ? 0u : (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
     const int64_t head_off = PAGED ? 0 : ((int64_t)b * Skv * Hkv + kvh) * kD;
-    // PAGED: the caches are addressed as arrays of 16-byte chunks (stride 16, indexed loads): a
-    // 32-bit chunk index reaches 64 GiB, and an index past the cache reads as zero like a row past
-    // Skv of a dense launch.
-    const unsigned pg_chunks_per_block = (unsigned)(16 * Hkv * 16);
+    // PAGED: a wave's four pieces of a tile are the 16 rows of ONE cache block, so the block is
+    // addressed through the buffer descriptor itself: base = cache + id * block bytes (64-bit
+    // scalar arithmetic, any cache size), num_records = the block's bytes, and a lane's 32-bit
+    // offset stays inside the block.  An id outside the pool gets num_records = 0 and reads as
+    // zero, like a row past Skv of a dense launch.
+    const unsigned pg_block_bytes = (unsigned)(16 * Hkv * kD * 2);
     // Piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
     // instruction: lane L writes LDS bytes [16 L, 16 L + 16) of the piece's 1 KiB, i.e. position
     // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
@@ -565,10 +576,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};
     // PAGED: a wave's four pieces of a tile are the 16 rows of ONE block of the sequence (block
     // 4 tile + wave), so its id is a scalar (read through the scalar cache, three tiles ahead) and a
-    // lane's chunk index is id * chunks_per_block + a lane constant per piece; rows of V past the
-    // context get index -1 (true zeros), K needs no such care (those scores are masked)
+    // lane's byte offset inside the block is a lane constant per piece; rows of V past the context
+    // get an offset past the block (true zeros), K needs no such care (those scores are masked)
     unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
-    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // first chunk of the wave's block in tiles t+1, t+2, t+3
+    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // id of the wave's block in tiles t+1, t+2, t+3
+    const unsigned long long pg_kbase = (unsigned long long)k, pg_vbase = (unsigned long long)v;
+    constexpr unsigned kPgOutOfBlock = 0x40000000u;  // an offset no block reaches (Hkv < 2^15)
     {
         const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
         const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
@@ -576,11 +589,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned r = 4u * j + rin;
-                dma_pk[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 16u + (pos ^ (r & 15u));
-                dma_pv[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 16u + (pos ^ (4u * rin));
+                dma_pk[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 256u + 16u * (pos ^ (r & 15u));
+                dma_pv[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 256u + 16u * (pos ^ (4u * rin));
             }
-            dma_krs = u32x4{(unsigned)ka, ((unsigned)(ka >> 32) & 0xffffu) | (16u << 16), num_cache_chunks, 0x00020000u};
-            dma_vrs = u32x4{(unsigned)va, ((unsigned)(va >> 32) & 0xffffu) | (16u << 16), num_cache_chunks, 0x00020000u};
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
@@ -593,7 +604,13 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     auto dma_id = [&](int tile) -> unsigned {
         int bi = 4 * (tile + tile0) + wave;
         bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
-        return (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi] * pg_chunks_per_block;
+        return (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
+    };
+    // PAGED: descriptor of block `id` of a cache (all scalar: the id came through the scalar cache)
+    auto pg_desc = [&](unsigned long long base, unsigned id) -> u32x4 {
+        const unsigned long long a = base + (unsigned long long)id * pg_block_bytes;
+        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, id < num_cache_blocks ? pg_block_bytes : 0u,
+                     0x00020000u};
     };
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
     auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u) {
@@ -601,17 +618,17 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
         const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + r0 * 256u;
         if constexpr (PAGED) {
-            const unsigned sbase = sid;  // block id * chunks per block (dma_id)
             if (j < 4) {
-                const unsigned idx = sbase + dma_pk[j];
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 idxen lds"
-                             : : "s"(dst), "v"(idx), "s"(dma_krs) : "memory");
+                const u32x4 rs = pg_desc(pg_kbase, sid);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
             } else {
+                const u32x4 rs = pg_desc(pg_vbase, sid);
                 const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
                 const int r = 4 * (j & 3) + (lane >> 4);
-                const unsigned idx = r < rows_left ? sbase + dma_pv[j & 3] : 0xffffffffu;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 idxen lds"
-                             : : "s"(dst), "v"(idx), "s"(dma_vrs) : "memory");
+                const unsigned off = r < rows_left ? dma_pv[j & 3] : kPgOutOfBlock;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             : : "s"(dst), "v"(off), "s"(rs) : "memory");
             }
         } else if (j < 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -954,10 +971,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     {
         unsigned id0 = 0;
         if constexpr (PAGED && !KSPLIT) {
-            id0 = early_id[0] * pg_chunks_per_block;
-            pg_s0 = early_id[1] * pg_chunks_per_block;
-            pg_s1 = early_id[2] * pg_chunks_per_block;
-            pg_s2 = early_id[3] * pg_chunks_per_block;
+            id0 = early_id[0];
+            pg_s0 = early_id[1];
+            pg_s1 = early_id[2];
+            pg_s2 = early_id[3];
         } else if constexpr (PAGED) {
             id0 = dma_id(0);
             pg_s0 = dma_id(1);
@@ -1354,7 +1371,7 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     const int pairs = (num_q_tiles + 1) / 2;
     // adjacent pairing once there are at least two workgroups per CU (MI355X: 256 CUs)
     int pair_adjacent = (int64_t)pairs * a.num_heads * a.batch >= (int64_t)2 * device_cus();
-    if (launch_policy().k1_pairing >= 0) pair_adjacent = launch_policy().k1_pairing;
+    if (const int forced = launch_policy().k1_pairing; forced >= 0) pair_adjacent = forced;
     const dim3 grid((unsigned)(pairs * a.num_heads), (unsigned)a.batch), block(64 * kWaves);
     const float scale_log2e = a.softmax_scale * 1.4426950408889634f;
     auto q = static_cast<const __bf16 *>(a.q);
@@ -1380,10 +1397,9 @@ bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a) {
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
     if (a.num_seqs <= 0 || a.num_seqs > 65535 || a.num_new_tokens <= 0) return false;
     if (a.max_blocks_per_seq <= 0 || a.max_blocks_per_seq > (1 << 26)) return false;
-    // 32-bit index of 16-byte chunks over one cache, block ids in 24 bits
-    const int64_t chunks = a.num_cache_blocks * 16 * a.num_kv_heads * 16;
-    if (a.num_cache_blocks <= 0 || a.num_cache_blocks >= (1 << 24) || chunks >= ((int64_t)1 << 32) ||
-        16 * a.num_kv_heads * 16 >= (1 << 24))
+    // a block is addressed through its own buffer descriptor (64-bit base, 32-bit offset inside the
+    // block), so the cache may have any size; ids are unsigned 32-bit values below num_cache_blocks
+    if (a.num_cache_blocks <= 0 || a.num_cache_blocks > (int64_t)0x7fffffff || a.num_kv_heads >= (1 << 15))
         return false;
     const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     return al(a.q) && al(a.k_cache) && al(a.v_cache) && al(a.out);
@@ -1438,10 +1454,10 @@ size_t flash_attn_paged_workspace_bytes(const PagedAttnArgs &a) {
 hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     const PagedGeom g = paged_geom(a);
     int pair_adjacent = (int64_t)g.pairs * g.units * a.num_seqs >= (int64_t)2 * device_cus();
-    if (launch_policy().k1_pairing >= 0) pair_adjacent = launch_policy().k1_pairing;
+    if (const int forced = launch_policy().k1_pairing; forced >= 0) pair_adjacent = forced;
     const dim3 block(64 * kWaves);
     const float scale_log2e = a.scale * 1.4426950408889634f;
-    const unsigned chunks = (unsigned)(a.num_cache_blocks * 16 * a.num_kv_heads * 16);
+    const unsigned pool = (unsigned)a.num_cache_blocks;
     auto q = static_cast<const __bf16 *>(a.q);
     auto kc = static_cast<const __bf16 *>(a.k_cache);
     auto vc = static_cast<const __bf16 *>(a.v_cache);
@@ -1456,7 +1472,7 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
         const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs), 1u, (unsigned)parts);
         flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(
             q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
-            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, ws,
+            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, ws,
             g.gsh, a.num_seqs);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
@@ -1473,7 +1489,7 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
 #endif
     flash_attn_mfma_kernel<true, true, false><<<grid, block, 0, stream>>>(
         q, kc, vc, o, lse_arg, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
-        pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, chunks, nullptr,
+        pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, nullptr,
         g.gsh, a.num_seqs);
     return hipGetLastError();
 }

@@ -13,7 +13,10 @@ namespace kernels {
 
 namespace {
 
-LaunchPolicy g_policy;
+// one relaxed atomic per field: launches and workspace queries read them without a lock and never
+// see a torn value; set / reset are serialised by g_mu
+constexpr int kNumFields = 9;
+std::atomic<int> g_values[kNumFields];
 std::once_flag g_once;
 std::mutex g_mu;
 
@@ -34,33 +37,44 @@ const Field kFields[] = {
     {"NVLLM_K1_KSPLIT", &LaunchPolicy::k1_ksplit, 0},
 };
 
+static_assert(sizeof(kFields) / sizeof(kFields[0]) == kNumFields, "one atomic per field");
+
+// values a launcher could not work with are brought into range here, once, not on a launch path
+int sanitise(const Field &f, int v) {
+    if (f.member == &LaunchPolicy::paged_wave_target && v < 1) return 1;
+    return v;
+}
+
 int parse(const Field &f, const char *s) {
     if (!s || !*s) return f.dflt;
     if (f.member == &LaunchPolicy::k1_pairing) {
         if (s[0] == 'a') return 1;
         if (s[0] == 'b') return 0;
     }
-    return std::atoi(s);
+    return sanitise(f, std::atoi(s));
 }
 
 void load_env() {
-    for (const Field &f : kFields) g_policy.*(f.member) = parse(f, std::getenv(f.name));
+    for (int i = 0; i < kNumFields; ++i)
+        g_values[i].store(parse(kFields[i], std::getenv(kFields[i].name)), std::memory_order_relaxed);
 }
 
 }  // namespace
 
-const LaunchPolicy &launch_policy() {
+LaunchPolicy launch_policy() {
     std::call_once(g_once, load_env);
-    return g_policy;
+    LaunchPolicy p{};
+    for (int i = 0; i < kNumFields; ++i) p.*(kFields[i].member) = g_values[i].load(std::memory_order_relaxed);
+    return p;
 }
 
 bool set_launch_policy(const char *name, int value) {
     if (!name) return false;
     std::call_once(g_once, load_env);
     std::lock_guard<std::mutex> lock(g_mu);
-    for (const Field &f : kFields)
-        if (std::strcmp(name, f.name) == 0) {
-            g_policy.*(f.member) = value;
+    for (int i = 0; i < kNumFields; ++i)
+        if (std::strcmp(name, kFields[i].name) == 0) {
+            g_values[i].store(sanitise(kFields[i], value), std::memory_order_relaxed);
             return true;
         }
     return false;

@@ -27,8 +27,11 @@ struct LaunchPolicy {
     int k1_pack;            // NVLLM_K1_PACK: 0 no head packing, -1 / 1 pack when the group allows
     int k1_ksplit;          // NVLLM_K1_KSPLIT: > 0 forces the key-split part count
 };
-const LaunchPolicy &launch_policy();
-// name = the environment variable's name; false if unknown
+// a snapshot by value (each field read atomically).  A workspace query and the launch it sizes see
+// the same policy unless nvllm_debug_set_policy runs between them: that hook is for tests and
+// tuning scripts and is not meant to race with launches in flight.
+LaunchPolicy launch_policy();
+// name = the environment variable's name; false if unknown.  NVLLM_PAGED_WAVE_TARGET is clamped to >= 1.
 bool set_launch_policy(const char *name, int value);
 void reset_launch_policy();  // back to the environment's values
 // compute units of the CURRENT device (cached per device id)
@@ -98,11 +101,18 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
 size_t paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_heads,
                                   int num_kv_heads, int head_dim, int block_size,
                                   int max_blocks_per_seq);
+// which kernel launch_paged_attn runs for these arguments (pointers may be null in a pure query:
+// a null pointer counts as aligned)
+enum class PagedPath : int { Decode = 0, K1Paged = 1, Generic = 2 };
+PagedPath paged_attn_path(DType dt, const PagedAttnArgs &a);
+// what THIS launch needs (<= paged_attn_workspace_bytes of its shape: 0 when the generic kernel runs)
+size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a);
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream);
 // the same launch with the split-K scratch in a file-scope device array of paged_attn.hip
 // (a.workspace is ignored); launches that need more than kNoAllocScratchBytes are refused
 constexpr size_t kNoAllocScratchBytes = (size_t)32 << 20;
 hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &a, hipStream_t stream);
+hipError_t noalloc_prepare_device();  // looks the scratch address of the current device up once
 // K1 over the paged cache (flash_attn_mfma.hip): chunked prefill / verify with more than 32 query
 // rows per kv head; launch_paged_attn dispatches to it
 bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a);

@@ -22,13 +22,17 @@
 //   workgroup walk the same block-table entries, so together they read the
 //   whole contiguous 16 x Hkv x 256 B block (DRAM-page friendly) while every
 //   wave keeps its own online-softmax state: no barriers, no cross-wave
-//   traffic.  Waves never share LDS; each has a private 8 KiB V staging tile.
+//   traffic.  Waves never share LDS; each has a private 16 KiB staging area:
+//   an 8 KiB K image and an 8 KiB V image of the current 32-token tile.
 //
 // Per wave, per 32-token tile (two 16-token blocks):
 //   S^T[token][row] = K[token][:] . Q[row][:]      8 x mfma_f32_16x16x32_bf16
-//       A = K: lane (g = lane>>4, c = lane&15) loads 16 B of token row c at
-//       dims 32s+8g.. for k-step s -- K goes HBM -> VGPR directly in MFMA
-//       operand layout (each load instruction covers 16 rows x 64 B).
+//       A = K: loaded like V with fully coalesced 16 B/lane loads (4 whole
+//       256 B rows per instruction; fragment-shaped loads of 16 rows x 64 B ask
+//       L2 for every 128 B line twice), written to the wave's K image with the
+//       16 B chunk ch of row r at position ch ^ r, and read back as
+//       row-per-lane A fragments (lane (g = lane>>4, c = lane&15): 16 B of token
+//       row c at dims 32s+8g.. for k-step s) with conflict-free ds_read_b128.
 //       B = Q^T: kept in VGPRs for the whole kernel.
 //   online softmax in the exp2 domain; state (m, l) lives in the lane that
 //       owns query row c, replicated over the four lane groups g (the row max
@@ -44,7 +48,8 @@
 //   Because O^T keeps the query row on the lane (col = lane&15), the rescale
 //   by alpha = 2^(m_old - m_new) and the final 1/l are lane-local.
 // Loads for tile i+1 are issued before tile i is consumed (register double
-// buffering, 16 KiB in flight per wave); block-table entries are fetched two
+// buffering, 16 KiB in flight per wave, then the ds_write into the two LDS
+// images); block-table entries are fetched two
 // tiles ahead with scalar loads.  Only the last tile(s) of a sequence take
 // the masked path (context tail, bottom-right causal mask for T > 1, V rows
 // past context_len zeroed so stale cache contents can never reach O).
@@ -679,11 +684,23 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
     return (int)splits;
 }
 
+PagedPath paged_attn_path(DType dt, const PagedAttnArgs &a) {
+    if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
+                             a.block_size, a.max_blocks_per_seq))
+        return PagedPath::Decode;
+    if (launch_policy().paged_flash != 0 && flash_attn_paged_supported(dt, a)) return PagedPath::K1Paged;
+    return PagedPath::Generic;
+}
+
+// An upper bound over everything the shape alone does not say (cache size, pointer alignment): the
+// launch may need less (the generic kernel needs none), never more.  The split factors depend on the
+// CU count of the CURRENT device: query with the launch device current.
 size_t paged_attn_workspace_bytes(int num_seqs, int T, int Hq, int Hkv, int D, int block_size,
                                   int max_blocks_per_seq) {
     if (!paged_attn_fast_path(DType::BF16, num_seqs, T, Hq, Hkv, D, block_size, max_blocks_per_seq)) {
         // more query rows per kv head than the decode kernel takes: the prefill kernel over the
         // cache, which splits the key walk of a small launch and needs room for the partials
+        if (launch_policy().paged_flash == 0) return 0;  // generic kernel: no workspace
         if (D == kD && block_size == kBS && Hkv > 0 && Hq % Hkv == 0 && T > 0 && num_seqs > 0) {
             PagedAttnArgs a{};
             a.num_seqs = num_seqs;
@@ -731,14 +748,18 @@ hipError_t noalloc_scratch(void **out) {
 }
 }  // namespace
 
+// resolves the scratch address of the current device ahead of the first launch (nvllm_set_device
+// calls it), so that no symbol lookup happens on a launch path -- e.g. under stream capture
+hipError_t noalloc_prepare_device() {
+    void *p = nullptr;
+    return noalloc_scratch(&p);
+}
+
 hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &args, hipStream_t stream) {
     PagedAttnArgs a = args;
     a.workspace = nullptr;
     a.workspace_bytes = 0;
-    const size_t need = dt == DType::BF16
-                            ? paged_attn_workspace_bytes(a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads,
-                                                         a.head_dim, a.block_size, a.max_blocks_per_seq)
-                            : 0;
+    const size_t need = paged_attn_launch_workspace_bytes(dt, a);
     if (need > kNoAllocScratchBytes) return hipErrorOutOfMemory;  // the C ABI rejects this before
     if (need > 0) {
         void *p = nullptr;
@@ -748,6 +769,12 @@ hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &args, hipStr
         a.workspace_bytes = kNoAllocScratchBytes;  // nothing in it has to start at zero
     }
     return launch_paged_attn(dt, a, stream);
+}
+
+size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a) {
+    if (dt != DType::BF16 || paged_attn_path(dt, a) == PagedPath::Generic) return 0;
+    return paged_attn_workspace_bytes(a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
+                                      a.block_size, a.max_blocks_per_seq);
 }
 
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {

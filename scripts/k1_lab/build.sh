@@ -6,7 +6,7 @@ ROOT=$(cd $HERE/../.. && pwd)
 CSRC=$ROOT/nano-vllm-rs_amd/csrc
 OUT=$HERE/_build
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -I$CSRC -I$ROOT/include -Wall -Wno-unused-function -fno-gpu-rdc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DNVLLM_K1_LAB -I$CSRC -I$ROOT/include -Wall -Wno-unused-function -fno-gpu-rdc"
 : > $OUT/variants.inc
 OBJS=""
 pids=""

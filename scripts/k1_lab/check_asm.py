@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Audit a K1 .s: no compiler-generated AGPR traffic outside inline-asm statements, no spills,
-no VALU write of an MFMA operand right in front of an MFMA, M0 only inside the LDS-DMA statements."""
+no VALU write of an MFMA operand right in front of an MFMA, M0 only inside the LDS-DMA statements,
+no VALU-written SGPR (v_readlane / v_readfirstlane: an SGPR spill reload) read as the descriptor or
+scalar offset of an LDS-DMA load within the 5 wait states the hardware needs."""
 import re, sys
 inasm = False
 bad = []
@@ -48,6 +50,28 @@ for k, (n, l) in enumerate(code):
         dmas += 1
         if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or code[k - 1][1] != 's_nop 0':
             m0bad.append((n, l))
+# VALU write of an SGPR -> VMEM read of it needs 5 wait states; hipcc pads its own instructions,
+# not the inside of an asm statement (which starts with s_mov m0 + s_nop 0 = 2 states)
+def sregs(tok):
+    m = re.match(r's\[(\d+):(\d+)\]', tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r's(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+shaz = []
+for k, (n, l) in enumerate(code):
+    if not re.search(r'buffer_load.* lds$', l): continue
+    ops = [t.strip() for t in l.split(None, 1)[1].split(',')]
+    used = sregs(ops[1]) | sregs(ops[2].split()[0])
+    states = 0
+    for back in range(1, 8):
+        if k - back < 0 or states >= 5: break
+        pn, pl = code[k - back]
+        if pl.startswith('v_readlane_b32') or pl.startswith('v_readfirstlane_b32'):
+            if sregs(pl.split(None, 1)[1].split(',')[0].strip()) & used: shaz.append((n, pl, l))
+        m = re.match(r's_nop (\d+)', pl)
+        states += (int(m.group(1)) + 1) if m else 1
+print("VALU-written SGPR -> LDS-DMA descriptor within 5 wait states:", len(shaz))
+for h in shaz[:6]: print(h)
 print("LDS-DMA loads:", dmas, " M0 uses outside / malformed DMA statements:", len(m0bad))
 for n, l in m0bad[:6]: print(n, l)
 print("VALU write -> MFMA operand within 2 instructions:", len(haz))
@@ -57,4 +81,4 @@ for n, l in bad[:10]: print(n, l)
 for key in ('.vgpr_spill_count', '.sgpr_spill_count', '.private_segment_fixed_size', '.vgpr_count', '.agpr_count', '.sgpr_count'):
     for line in open(sys.argv[1]):
         if key in line: print(line.strip())
-sys.exit(1 if (bad or haz or m0bad) else 0)
+sys.exit(1 if (bad or haz or m0bad or shaz) else 0)

@@ -16,6 +16,11 @@ hipError_t launch_qk_norm_rope_cache(DType, const QkNormRopeCacheArgs &, hipStre
 bool paged_attn_fast_path(DType, int, int, int, int, int, int, int) { return false; }
 int paged_attn_num_splits(int, int, int) { return 1; }
 size_t paged_attn_workspace_bytes(int num_seqs, int, int, int, int, int, int) { return num_seqs == 7 ? 4096 : 0; }
+size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a) {
+    return dt == DType::BF16 ? paged_attn_workspace_bytes(a.num_seqs, 0, 0, 0, 0, 0, 0) : 0;
+}
+PagedPath paged_attn_path(DType, const PagedAttnArgs &) { return PagedPath::Generic; }
+hipError_t noalloc_prepare_device() { return hipSuccess; }
 hipError_t launch_paged_attn(DType, const PagedAttnArgs &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_paged_attn_noalloc(DType, const PagedAttnArgs &, hipStream_t) { return hipErrorNoDevice; }
 bool flash_attn_paged_supported(DType, const PagedAttnArgs &) { return false; }

@@ -101,3 +101,50 @@ def test_no_launch_path_reads_the_environment():
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".cpp", ".hpp")) and f != "launch_policy.cpp":
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_paged_attn_path_query_without_gpu():
+    """nvllm_paged_attn_path is a pure function of the launch shape: decode kernel up to 48 query
+    rows per kv head, the prefill kernel over the cache beyond -- on ANY cache size, the 2 Mi-block
+    (64 GiB) pool of BASELINE config 5 included -- and the generic kernel for other head shapes."""
+    pool5 = 2 * 1024 * 1024
+    assert nv.paged_attention_path(256, 1, 32, 8, 128, 16, 128, 40960) == "decode"
+    assert nv.paged_attention_path(1024, 1, 32, 8, 128, 16, 2048, pool5) == "decode"
+    assert nv.paged_attention_path(256, 4, 32, 8, 128, 16, 128, 40960) == "decode"
+    for T in (13, 16, 64, 512):
+        assert nv.paged_attention_path(32, T, 32, 8, 128, 16, 256, pool5) == "k1_paged"
+        assert nv.paged_attention_path(32, T, 32, 8, 128, 16, 256, 8 * pool5) == "k1_paged"
+    assert nv.paged_attention_path(4, 1, 4, 2, 8, 4, 3, 8) == "generic"            # reference test shape
+    assert nv.paged_attention_path(4, 64, 32, 8, 128, 16, 64, 4096, dtype=None) == "generic"  # f32
+    L = nv.capi.lib()
+    assert L.nvllm_paged_attn_path(0, 1, 32, 8, 128, 16, 4, 8, 0) == nv.capi.NVLLM_ERR_CONFIG
+    assert L.nvllm_paged_attn_path(1, 1, 32, 5, 128, 16, 4, 8, 0) == nv.capi.NVLLM_ERR_CONFIG
+    # NVLLM_PAGED_FLASH=0 pins long launches to the generic kernel; the workspace query follows
+    try:
+        assert L.nvllm_paged_attn_workspace_bytes(1, 16, 32, 8, 128, 16, 256) > 0
+        assert L.nvllm_debug_set_policy(b"NVLLM_PAGED_FLASH", 0) == 0
+        assert nv.paged_attention_path(32, 64, 32, 8, 128, 16, 256, pool5) == "generic"
+        assert L.nvllm_paged_attn_workspace_bytes(1, 16, 32, 8, 128, 16, 256) == 0
+        # a wave target below 1 would divide by zero in the split arithmetic: clamped
+        assert L.nvllm_debug_set_policy(b"NVLLM_PAGED_WAVE_TARGET", -5) == 0
+        assert L.nvllm_paged_attn_workspace_bytes(16, 1, 32, 8, 128, 16, 128) == 0
+    finally:
+        L.nvllm_debug_reset_policy()
+
+
+def test_product_build_defines_no_lab_switch():
+    """The K1 source carries lab switches (cycle stamps, ablations that give wrong results by design).
+    They compile only under -DNVLLM_K1_LAB (an #error otherwise), and neither the product build
+    (build.py) nor the Rust build script (rust/build.rs) may define any of them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nvllm_build", os.path.join(ROOT, "nano-vllm-rs_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    banned = re.compile(r"K1_ABL_|NVLLM_K1_STAMPS|NVLLM_K1_LAB|K1_FINE|K1_RT|K1_DBG_")
+    assert not any(banned.search(f) for f in b.FLAGS), b.FLAGS
+    assert not banned.search(open(os.path.join(ROOT, "rust", "build.rs")).read())
+    assert not banned.search(open(os.path.join(ROOT, "nano-vllm-rs_amd", "build.py")).read())
+    src = open(os.path.join(ROOT, "nano-vllm-rs_amd", "csrc", "flash_attn_mfma.hip")).read()
+    guard = src[src.index("#if !defined(NVLLM_K1_LAB)"):src.index("#endif", src.index("#if !defined(NVLLM_K1_LAB)"))]
+    for name in set(re.findall(r"#if(?:def| defined)\s*\(?\s*((?:K1_|NVLLM_K1_)[A-Z_0-9]+)", src)) - {"NVLLM_K1_LAB"}:
+        assert name in guard, "lab switch %s is not covered by the #error guard" % name

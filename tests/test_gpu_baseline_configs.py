@@ -73,7 +73,7 @@ def test_config4_full_size_shared_prefix_verify(dev):
     assert np.isfinite(got).all()
 
 
-def _long_case(dev, N, ctx, pool_blocks, seed):
+def _long_case(dev, N, ctx, pool_blocks, seed, T=1):
     """Config 5 shape: N sequences x ctx tokens whose block ids are drawn from the WHOLE
     pool_blocks range (2 Mi blocks = 64 GiB per cache: the pool config 5 needs at 1024 sequences).
     Only the blocks the tables touch are filled; the rest of the pool stays uninitialised."""
@@ -89,41 +89,107 @@ def _long_case(dev, N, ctx, pool_blocks, seed):
         sl = idx[b:b + step]
         kc[sl] = torch.randn((sl.numel(), bs, Hkv, D), device=dev, dtype=torch.bfloat16)
         vc[sl] = torch.randn((sl.numel(), bs, Hkv, D), device=dev, dtype=torch.bfloat16)
-    q = torch.randn((N, 1, Hq, D), device=dev, dtype=torch.bfloat16)
+    q = torch.randn((N, T, Hq, D), device=dev, dtype=torch.bfloat16)
     return dict(q=q, caches=[(kc, vc)], block_tables=tables.to(dev).contiguous(),
                 context_lens=torch.full((N,), ctx, dtype=torch.int32, device=dev),
                 tables_np=tables.numpy())
 
 
 def _f32_reference(case, i, ctx):
-    """softmax(q k^T * scale) v in float32 on the device, for one decode sequence."""
+    """softmax(q k^T * scale + bottom-right causal mask) v in float32 on the device, for one
+    sequence with T new tokens (paged.rs:357-381: query t sits at position ctx - T + t)."""
     kc, vc = case["caches"][0]
     idx = torch.from_numpy(case["tables_np"][i].astype(np.int64)).to(kc.device)
-    k = kc[idx].reshape(-1, Hkv, D)[:ctx].float().repeat_interleave(Hq // Hkv, dim=1)
-    v = vc[idx].reshape(-1, Hkv, D)[:ctx].float().repeat_interleave(Hq // Hkv, dim=1)
-    s = torch.einsum("hd,shd->hs", case["q"][i, 0].float(), k) * SCALE
-    return torch.einsum("hs,shd->hd", torch.softmax(s, dim=-1), v).reshape(1, Hq * D)
+    G = Hq // Hkv
+    T = case["q"].shape[1]
+    k = kc[idx].reshape(-1, Hkv, D)[:ctx].float()                     # [S, Hkv, D]
+    v = vc[idx].reshape(-1, Hkv, D)[:ctx].float()
+    q = case["q"][i].float().reshape(T, Hkv, G, D)
+    s = torch.einsum("tkgd,skd->tkgs", q, k) * SCALE                  # [T, Hkv, G, S]
+    if T > 1:
+        pos = torch.arange(ctx, device=kc.device)[None, :] > (ctx - T + torch.arange(T, device=kc.device))[:, None]
+        s = s.masked_fill(pos[:, None, None, :], float("-inf"))
+    return torch.einsum("tkgs,skd->tkgd", torch.softmax(s, dim=-1), v).reshape(1, T, Hq * D)
 
 
-@pytest.mark.parametrize("N,expect_splits", [(8, 32), (128, 2)])
+@pytest.mark.parametrize("N,expect_splits", [(8, 32), (128, 2), (256, 1)])
 def test_config5_long_context_decode(dev, N, expect_splits):
     """32,768-token contexts, max_blocks_per_seq 2048, block ids up to 2 Mi: 8 sequences (deep
-    split-K: 32 splits + merge) checked on every sequence by the oracle, and 128 sequences
-    (splits == 2, the merge pass of a full-rate launch) on a sample; every sequence of both
-    also against the float32 formula."""
+    split-K: 32 splits + merge) checked on every sequence by the oracle, 128 sequences
+    (splits == 2, the merge pass of a full-rate launch) and 256 sequences (splits == 1: the
+    launch BASELINE config 5 itself makes at 1024 sequences -- one wave walks all 1024 tiles of
+    its sequence, no workspace, no merge) on a sample; every sequence of all three also against
+    the float32 formula."""
     ctx, pool = 32768, 2 * 1024 * 1024
     case = _long_case(dev, N, ctx, pool, 5 + N)
     assert int(case["tables_np"].max()) > 2_000_000 and case["tables_np"].shape[1] == 2048
     L = nv.capi.lib()
     need = L.nvllm_paged_attn_workspace_bytes(N, 1, Hq, Hkv, D, bs, 2048)
-    assert need == N * Hq * expect_splits * (D + 2) * 4
+    assert need == (N * Hq * expect_splits * (D + 2) * 4 if expect_splits > 1 else 0)
+    assert nv.paged_attention_path(N, 1, Hq, Hkv, D, bs, 2048, pool) == "decode"
     got = _launch(case, 1).float().cpu().numpy()
     assert np.isfinite(got).all()
     sample = list(range(N)) if N <= 8 else [0, 37, 90, N - 1]
     want = _oracle_rows(case, case["q"], ctx, 1, sample)
     assert_attention_close(got[sample], want)
     ref = torch.cat([_f32_reference(case, i, ctx) for i in range(N)], 0).cpu().numpy()
-    assert_attention_close(got.reshape(N, -1), ref)
+    assert_attention_close(got.reshape(N, -1), ref.reshape(N, -1))
+
+
+def _launch_us(case, rounds=15):
+    """median HIP-event time of one launch, microseconds (workspace allocated once, outside)"""
+    kc, vc = case["caches"][0]
+    N, T = case["q"].shape[0], case["q"].shape[1]
+    need = nv.capi.lib().nvllm_paged_attn_workspace_bytes(N, T, Hq, Hkv, D, bs, case["block_tables"].shape[1])
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=kc.device) if need else None
+    times = []
+    for r in range(rounds + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nv.paged_attention_batched(case["q"], kc, vc, case["block_tables"], case["context_lens"], SCALE, workspace=ws)
+        e1.record()
+        e1.synchronize()
+        if r >= 3:
+            times.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(times))
+
+
+@pytest.mark.parametrize("T", [16, 64])
+def test_k1_over_the_cache_on_the_config5_pool(dev, T):
+    """A verify / prefill chunk (src/speculative/engine.rs:146-169 verifies K+1 positions against the
+    whole cached context; paged.rs:357-381 is its mask) against the 2 Mi-block pool of config 5:
+    64 GiB per cache, past what a 32-bit index of 16-byte chunks reaches.  The launch must stay on
+    the prefill kernel over the cache (not the scalar generic kernel), match the oracle on sampled
+    sequences and the float32 formula on all, and take no longer than 1.2 x the same shape on a
+    pool that holds just its own blocks."""
+    N, ctx, pool = 32, 4096, 2 * 1024 * 1024
+    assert nv.paged_attention_path(N, T, Hq, Hkv, D, bs, ctx // bs, pool) == "k1_paged"
+    assert nv.capi.lib().nvllm_kv_cache_layer_bytes(pool, bs, Hkv, D, 0) == 64 << 30
+    case = _long_case(dev, N, ctx, pool, 500 + T, T=T)
+    case["context_lens"] = torch.tensor([ctx - 13 * (i % 7) for i in range(N)], dtype=torch.int32, device=dev)
+    ctxs = case["context_lens"].cpu().tolist()
+    assert int(case["tables_np"].max()) > 2_000_000
+    got = _launch(case, T).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    kc, vc = case["caches"][0]
+    outs = []
+    sample = [0, 13, N - 1]
+    for i in sample:
+        idx = torch.from_numpy(case["tables_np"][i].astype(np.int64)).to(dev)
+        outs.append(oracle.paged_attention(case["q"][i:i + 1].float().cpu().numpy(), kc[idx].float().cpu().numpy(),
+                                           vc[idx].float().cpu().numpy(), list(range(ctx // bs)), bs, ctxs[i],
+                                           Hq, Hkv, D, SCALE))
+    assert_attention_close(got[sample], np.concatenate(outs, 0))
+    ref = torch.cat([_f32_reference(case, i, ctxs[i]) for i in range(N)], 0).cpu().numpy()
+    assert_attention_close(got, ref)
+    t_big = _launch_us(case)
+    del case, kc, vc
+    torch.cuda.empty_cache()
+    small = _long_case(dev, N, ctx, N * (ctx // bs) + 64, 500 + T, T=T)
+    small["context_lens"] = torch.tensor(ctxs, dtype=torch.int32, device=dev)
+    t_small = _launch_us(small)
+    print("K1 over the cache, %d x %d, T = %d: 2 Mi-block pool %.1f us, own-blocks pool %.1f us" % (N, ctx, T, t_big, t_small))
+    assert t_big <= 1.2 * t_small, (t_big, t_small)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

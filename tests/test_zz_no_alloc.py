@@ -62,6 +62,34 @@ def test_noalloc_equals_the_workspace_entry_on_two_calls_in_a_row(dev):
         assert_attention_close(out.float().cpu().numpy(), oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, SCALE))
 
 
+def test_noalloc_through_the_prefill_kernels_key_split(dev):
+    """T = 16 new tokens of ONE sequence against 4096 / 1500 cached keys: 64 query rows per kv head go
+    to the prefill kernel over the cache, which splits the key walk of so small a launch (parts > 1)
+    and leaves its partials -- bf16 O, f32 (m, l), another slot layout than the decode kernel's
+    split-K -- in the same built-in scratch.  Two calls in a row, the second smaller (fewer key
+    tiles: some parts of some rows carry l = 0 over the first call's leftovers)."""
+    T = 16
+    big = _case(dev, 11, [4096], T, 300)
+    small = _case(dev, 12, [1500], T, 120)
+    for c in (big, small):
+        assert nv.paged_attention_path(1, T, Hq, Hkv, D, bs, c["bt"].shape[1], c["kc"].shape[0]) == "k1_paged"
+        assert _need(c) > 0
+    outs = []
+    for c in (big, small):
+        out = torch.full((1, T, Hq * D), float("nan"), dtype=torch.bfloat16, device=dev)
+        before = torch.cuda.memory_allocated(dev)
+        assert _noalloc(c, out) == 0, nv.capi.last_error()
+        assert torch.cuda.memory_allocated(dev) == before
+        outs.append(out)
+    torch.cuda.synchronize()
+    for c, out in zip((big, small), outs):
+        want = nv.paged_attention_batched(c["q"], c["kc"], c["vc"], c["bt"], c["cl"], SCALE)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        q, kc, vc, tables, ctx_lens = c["host"]
+        assert_attention_close(out.float().cpu().numpy(), oracle_paged_batch(q, kc, vc, tables, ctx_lens, bs, SCALE))
+
+
 def test_noalloc_without_scratch_and_beyond_the_limit(dev):
     L = nv.capi.lib()
     # a shape that needs no workspace: identical too (the scratch is never touched)
