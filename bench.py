@@ -2,6 +2,7 @@
 """bench.py -- throughput of the attention hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|shared|long|verify|prefill|kvwrite|producer]
+                    [--parallelism sequences|heads]
 
 `python bench.py --gpus N` with N > 1 starts N fresh rank processes itself (through
 torch.distributed.run on 127.0.0.1; the parent touches no GPU API); started under
@@ -18,7 +19,16 @@ in HBM before the timed region.
 For N > 1 (launched by torch.distributed.run, one rank per GPU) the sequences
 are sharded: every rank owns its own 256 sequences, block pool and cache -- no
 data-path collective ("weak" scaling); value = bytes all ranks processed / the
-max-over-ranks time.
+max-over-ranks time.  `--workload long` divides config 5's fixed 1024 sequences
+over the ranks ("strong" scaling, still no collective).
+
+`--parallelism heads` (N a divisor of the 8 KV heads) is north_star's second
+mode: every rank holds KV heads [r*8/N, (r+1)*8/N) of EVERY block (cache
+[num_blocks, 16, 8/N, 128]), computes the matching 32/N query heads of ALL
+sequences and then ONE all_gather_into_tensor (RCCL over xGMI) inside the timed
+step assembles [num_seqs, T, 32*128] on every rank ("strong" scaling: the total
+work is fixed).  The line then carries the kernel time and the collective time
+per step separately (HIP events) and `rccl_ranks_seen`.
 
 One JSON line is printed by rank 0.  `roofline` is the dominant kernel's
 algorithmic bytes (or FLOPs) per launch / its average launch duration measured
@@ -52,6 +62,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="decode",
                     choices=["decode", "shared", "long", "verify", "prefill", "kvwrite", "producer"])
+    ap.add_argument("--parallelism", default="sequences", choices=["sequences", "heads"],
+                    help="N > 1: shard sequences (no collective) or KV-head groups (+ one all-gather per step)")
     ap.add_argument("--tokens", type=int, default=8, help="new tokens per sequence (--workload verify)")
     ap.add_argument("--num-seqs", type=int, default=0)
     ap.add_argument("--ctx", type=int, default=0)
@@ -109,13 +121,26 @@ def launcher_check(args):
     if rank == args.launcher_check_fail_rank:
         raise SystemExit(3)
     seen = torch.ones(1, dtype=torch.int64)
+    extra = {}
+    if args.parallelism == "heads":
+        # the head-sharded step's collective through the product code (sharding.all_gather_heads),
+        # on a tensor that says which rank and head every column came from
+        import nano_vllm_rs_amd as nv
+        Hq, Hkv, D, N, T = 32, 8, 128, 3, 2
+        if Hkv % world != 0:
+            raise SystemExit("--parallelism heads needs --gpus to divide the %d KV heads" % Hkv)
+        b, e = nv.sharding.q_head_range(Hq, Hkv, world, rank)
+        local = torch.arange(b, e, dtype=torch.float32).repeat_interleave(D).expand(N, T, (e - b) * D).contiguous()
+        full = nv.sharding.all_gather_heads(local, D) if world > 1 else local
+        want = torch.arange(Hq, dtype=torch.float32).repeat_interleave(D).expand(N, T, Hq * D)
+        extra = dict(parallelism="heads", gathered_shape=list(full.shape), heads_in_order=bool(torch.equal(full, want)))
     if world > 1:
         dist.all_reduce(seen)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(dict(launcher_check=True, world=world, ranks_seen=int(seen.item()),
-                              workload=args.workload)))
+                              workload=args.workload, **extra)))
     return 0
 
 
@@ -174,6 +199,20 @@ def timed_loop(fn, steps, warmup, world, dev):
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1) / steps
     return max_over_ranks(wall, world, dev), max_over_ranks(ev_ms, world, dev)
+
+
+def per_launch_ms(fn, steps):
+    """Per-launch durations from one HIP-event pair around every launch (a pass of its own, after
+    the timed region: an event record between launches costs host time the timed loop must not
+    pay).  Returns (median, min) in ms."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        fn(i)
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
 
 
 # ------------------------------------------------------------------------------------------
@@ -256,6 +295,9 @@ def cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget_s, bytes_per
 def run_decode(args, nv, dev, rank, world, workload):
     Hq, Hkv, D, bs = 32, 8, 128, 16
     scale = 1.0 / math.sqrt(D)
+    heads_mode = args.parallelism == "heads"
+    if heads_mode and Hkv % world != 0:
+        raise SystemExit("--parallelism heads needs --gpus to divide the %d KV heads" % Hkv)
     if workload == "decode":      # BASELINE config 3
         num_seqs, ctx, T, shared = args.num_seqs or 256, args.ctx or 2048, 1, 0
         layers = args.layers or 4
@@ -274,12 +316,22 @@ def run_decode(args, nv, dev, rank, world, workload):
         name = "verify: %d seqs x %d ctx, T=%d new tokens, 32Q/8KV, hd128, block 16" % (num_seqs, ctx, T)
     else:                          # BASELINE config 5 (per-GPU shard of 1024/n sequences)
         total = args.num_seqs or 1024
-        num_seqs, ctx, T, shared = max(total // max(args.gpus, 1), 1), args.ctx or 32768, 1, 0
+        per = total if heads_mode else max(total // max(args.gpus, 1), 1)
+        num_seqs, ctx, T, shared = per, args.ctx or 32768, 1, 0
         layers = args.layers or 1
         pool = None
-        name = ("config5: long-context paged decode, %d seqs/GPU x %d ctx (1024 total sharded %d-way)"
-                % (num_seqs, ctx, args.gpus))
-    case = build_decode_case(nv, dev, 3 + rank, num_seqs, ctx, T, Hq, Hkv, D, bs, layers, shared, pool)
+        name = ("config5: long-context paged decode, %d seqs/GPU x %d ctx (%d total, %s-sharded %d-way)"
+                % (num_seqs, ctx, total, "kv-head" if heads_mode else "sequence", args.gpus))
+    if heads_mode:
+        # every rank: ALL sequences (same tables on every rank: the seed does not depend on the
+        # rank), its Hkv/n KV heads of every block, its Hq/n query heads
+        Hq_l, Hkv_l, seed = Hq // world, Hkv // world, 3
+        name += "; kv-head-sharded x%d: cache [nb,16,%d,128] per rank + one all-gather" % (world, Hkv_l)
+    else:
+        Hq_l, Hkv_l, seed = Hq, Hkv, 3 + rank
+    case = build_decode_case(nv, dev, seed, num_seqs, ctx, T, Hq_l, Hkv_l, D, bs, layers, shared, pool)
+    Hq_full, Hkv_full = Hq, Hkv
+    Hq, Hkv = Hq_l, Hkv_l          # what this rank's launch sees
     token_bytes = 2 * Hkv * D * 2
     logical_bytes = num_seqs * ctx * token_bytes
     unique_bytes = case["unique_blocks"] * bs * token_bytes
@@ -289,12 +341,39 @@ def run_decode(args, nv, dev, rank, world, workload):
     ws = torch.empty(int(need), dtype=torch.uint8, device=dev) if need else None
     outs = [None]
 
-    def step(i):
+    def kernel_step(i):
         kc, vc = case["caches"][i % layers]
         outs[0] = nv.paged_attention_batched(case["q"], kc, vc, case["block_tables"],
                                              case["context_lens"], scale, workspace=ws)
 
+    def step(i):
+        kernel_step(i)
+        if heads_mode and world > 1:
+            outs[0] = nv.sharding.all_gather_heads(outs[0], D)      # [num_seqs, T, Hq_full * D]
+
     wall, ev_ms = timed_loop(step, args.steps, args.warmup, world, dev)
+    split = None
+    if heads_mode:
+        # the same step, kernel and collective bracketed separately (a pass of its own: three event
+        # records per step are host work the timed loop does not carry)
+        n = min(args.steps, 50)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        barrier(world)
+        for i, (e0, e1, e2) in enumerate(evs):
+            e0.record()
+            kernel_step(i)
+            e1.record()
+            if world > 1:
+                outs[0] = nv.sharding.all_gather_heads(outs[0], D)
+            e2.record()
+        torch.cuda.synchronize()
+        k_ms = sorted(e0.elapsed_time(e1) for e0, e1, _ in evs)[n // 2]
+        c_ms = sorted(e1.elapsed_time(e2) for _, e1, e2 in evs)[n // 2]
+        split = dict(kernel_ms_median=max_over_ranks(k_ms, world, dev),
+                     collective_ms_median=max_over_ranks(c_ms, world, dev), steps=n,
+                     collective="all_gather_into_tensor, %d bytes per rank" % (num_seqs * T * Hq * D * 2),
+                     output_shape=list(outs[0].shape))
+        assert outs[0].shape[-1] == Hq_full * D
     algo_bytes = unique_bytes  # roofline numerator: bytes that must come from HBM
     res = dict(
         metric="paged_decode_attn_GBps", unit="GB/s",
@@ -303,7 +382,8 @@ def run_decode(args, nv, dev, rank, world, workload):
         config=dict(workload=name, num_seqs_per_gpu=num_seqs, context_len=ctx, new_tokens=T,
                     num_q_heads=Hq, num_kv_heads=Hkv, head_dim=D, block_size=bs,
                     layer_caches_rotated=layers, pool_blocks=case["pool_blocks"],
-                    parallelism="sequence-sharded x%d (no collective)" % world,
+                    parallelism=("kv-head-sharded x%d (one RCCL all-gather per step)" % world if heads_mode
+                                 else "sequence-sharded x%d (no collective)" % world),
                     algorithmic_bytes_per_step_per_gpu=algo_bytes,
                     logical_bytes_per_step_per_gpu=logical_bytes, qo_table_bytes=aux_bytes),
         roofline=dict(bound="hbm", achieved=algo_bytes / (ev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
@@ -311,7 +391,16 @@ def run_decode(args, nv, dev, rank, world, workload):
                       traffic=None, kernel="paged_attn_kernel",
                       launch_ms=ev_ms, effective_logical_GBps=logical_bytes / (ev_ms * 1e-3) / 1e9),
     )
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
+    # per-GPU work fixed as N grows -> weak; a fixed total divided over the ranks -> strong
+    res["scaling"] = "strong" if (heads_mode or workload == "long") else "weak"
+    if split is not None:
+        res["head_sharded_step"] = split
+        # in head mode the roofline figure is the kernel's own time, the step adds the collective
+        res["roofline"]["launch_ms"] = split["kernel_ms_median"]
+        res["roofline"]["achieved"] = algo_bytes / (split["kernel_ms_median"] * 1e-3) / 1e9
+        res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+        res["roofline"]["step_ms_with_collective"] = ev_ms
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not heads_mode:   # the CPU leg runs at N=1 only
         budget = args.cpu_seconds if workload != "long" else args.cpu_seconds
         cb, want = cpu_baseline_decode(case, ctx, T, Hq, Hkv, D, bs, scale, budget,
                                        ctx * token_bytes)
@@ -340,6 +429,7 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
         outs[0] = nv.flash_attention(q, k, v, cfg)
 
     wall, ev_ms = timed_loop(step, steps, warmup, world, dev)
+    med_ms, min_ms = per_launch_ms(step, min(steps, 200))
     flops = 4.0 * B * Hq * S * S * D * 0.5   # causal: 68.72 GFLOP at B=1,S=4096
     res = dict(
         metric="prefill_flash_attn_TFLOPs", unit="TFLOP/s",
@@ -348,8 +438,12 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
                     algorithmic_flops_per_step_per_gpu=flops, parallelism="replicas x%d" % world),
         roofline=dict(bound="mfma", achieved=flops / (ev_ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS,
                       unit="TFLOP/s", frac=flops / (ev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                      traffic=None, kernel="flash_attn", launch_ms=ev_ms),
+                      traffic=None, kernel="flash_attn_mfma_kernel", launch_ms=ev_ms,
+                      launch_ms_median=med_ms, launch_ms_min=min_ms,
+                      achieved_at_median=flops / (med_ms * 1e-3) / 1e12),
     )
+    if B == 1 and S == 4096:
+        res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic("config2_prefill")
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         import oracle
         # sample: every head of batch element 0 (the whole workload at B=1), repeated to ~budget
@@ -435,16 +529,22 @@ def run_producer(args, nv, dev, rank, world, steps, warmup, num_tokens):
                               traffic=None, kernel="qk_norm_rope_cache_d128_kernel", launch_ms=ev_ms))
 
 
+PMC_TRAFFIC_FILES = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+
+
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled
-    per the gfx950 correction).  Counters cannot be read inside this process; None if the
-    workload was not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f)[key]["traffic_bytes"]
-    except Exception:
-        return None
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The bytes are
+    NOT measured in this run -- counters cannot be read inside the process: they come from the
+    committed rocprofv3 PMC passes over this same command (FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH doubled per the gfx950 correction), newest file first.  (None, None) if the workload
+    was not profiled."""
+    for rel in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return json.load(f)[key]["traffic_bytes"], rel + " (committed rocprofv3 --pmc passes, not this run)"
+        except Exception:
+            continue
+    return None, None
 
 
 def main(argv=None):
@@ -462,7 +562,7 @@ def main(argv=None):
     if args.workload in ("decode", "shared", "long", "verify"):
         res = run_decode(args, nv, dev, rank, world, args.workload)
         if args.workload == "decode" and not args.num_seqs and not args.ctx:
-            res["roofline"]["traffic"] = pmc_traffic("config3_decode")
+            res["roofline"]["traffic"], res["roofline"]["traffic_source"] = pmc_traffic("config3_decode")
     elif args.workload == "prefill":
         res = run_prefill(args, nv, dev, rank, world, args.steps, args.warmup)
     elif args.workload == "producer":
@@ -472,7 +572,7 @@ def main(argv=None):
     also = {}
     if args.workload == "decode" and not args.no_also and world == 1:
         torch.cuda.empty_cache()
-        p = run_prefill(args, nv, dev, rank, world, max(args.steps // 10, 5), max(args.warmup // 10, 2))
+        p = run_prefill(args, nv, dev, rank, world, max(args.steps, 20), max(args.warmup // 2, 5))
         also["prefill"] = {k: p[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline", "config")
                            if k in p}
         if "cpu_baseline" in p:
@@ -499,7 +599,8 @@ def main(argv=None):
     props = torch.cuda.get_device_properties(dev)
     line = dict(
         metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=world, steps=args.steps,
-        warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak",
+        warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True,
+        scaling=res.get("scaling", "weak"),
         vs_baseline=None, dtype="bf16", data="synthetic", config=res["config"], roofline=res["roofline"],
         cpu_baseline=res.get("cpu_baseline"),
         device=dict(name=props.name, cus=props.multi_processor_count,
@@ -508,6 +609,8 @@ def main(argv=None):
     )
     if also:
         line["also"] = also
+    if "head_sharded_step" in res:
+        line["head_sharded_step"] = res["head_sharded_step"]
     if world > 1:
         line["rccl_ranks_seen"] = rccl_seen
     if rank == 0:

@@ -14,9 +14,63 @@ CPU tests).  Two modes:
     `all_gather_heads` then assembles [num_seqs, T, Hq*D] with ONE all-gather per layer.  The
     per-rank message is num_seqs*T*(Hq/n)*D*2 bytes (256 KiB at config 3, n = 8): on the 7-link
     xGMI mesh that is latency-bound, so it is a single collective, never a ring of small ones.
+
+Prefix-shared sequences (BASELINE config 4) should live on ONE rank, or every rank that holds
+one of them caches a copy of the shared blocks: `shard_by_prefix` / `partition_by_prefix` place a
+sequence by the prefix hash of its first block, the value `BlockManager::allocate_with_prefix`
+(reference src/core/block_manager.rs:337-347) keys its prefix cache on.
 """
 import torch
 import torch.distributed as dist
+
+_MASK64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser: spreads a 64-bit hash over its low bits before the modulo."""
+    x &= _MASK64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & _MASK64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & _MASK64
+    return x ^ (x >> 31)
+
+
+def shard_by_prefix(first_block_hash, world, seq_id=0):
+    """Rank that owns a sequence, from the prefix hash of its FIRST full block
+    (`hash_token_block(tokens[:block_size], None)`, block.rs:43-57): every sequence that starts
+    with the same block lands on the same rank, so the blocks they share through
+    `allocate_with_prefix` (block_manager.rs:337-347) exist on one GPU only.  A sequence shorter
+    than one block has no hash (None) and nothing to share: it goes by `seq_id`.  Stateless (an
+    admission-time rule); `partition_by_prefix` balances a known batch."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    if first_block_hash is None:
+        return int(seq_id) % world
+    return _mix64(int(first_block_hash)) % world
+
+
+def partition_by_prefix(first_block_hashes, world):
+    """Balanced placement of a known batch: sequences are grouped by first-block hash (None =
+    a group of its own), the groups are dealt largest first to the least loaded rank (ties: lowest
+    rank).  Returns `world` lists of sequence indices, each in ascending order.  Co-location is
+    kept (a group is never split); the load differs by at most the largest group."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    groups, order = {}, []
+    for i, h in enumerate(first_block_hashes):
+        key = ("seq", i) if h is None else ("hash", int(h))
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(i)
+    order.sort(key=lambda k: (-len(groups[k]), groups[k][0]))
+    ranks, load = [[] for _ in range(world)], [0] * world
+    for key in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        ranks[r].extend(groups[key])
+        load[r] += len(groups[key])
+    return [sorted(r) for r in ranks]
 
 
 def sequence_range(num_seqs, world, rank):

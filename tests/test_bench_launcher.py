@@ -32,6 +32,31 @@ def test_plain_invocation_self_launches_two_ranks():
     assert line == dict(launcher_check=True, world=2, ranks_seen=2, workload="long")
 
 
+def test_head_sharded_mode_self_launches_and_gathers_in_head_order():
+    """--parallelism heads: the launcher path is the same; the rehearsal runs the step's one
+    collective (sharding.all_gather_heads) over gloo and checks that rank r's heads land in
+    columns [r * Hq/n * D, (r + 1) * Hq/n * D)."""
+    r = _run("--gpus", "2", "--launcher-check", "--parallelism", "heads")
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = _json_line(r.stdout)
+    assert line["world"] == 2 and line["ranks_seen"] == 2 and line["parallelism"] == "heads"
+    assert line["gathered_shape"] == [3, 2, 32 * 128] and line["heads_in_order"] is True
+    r = _run("--gpus", "4", "--launcher-check", "--parallelism", "heads")
+    assert r.returncode == 0 and _json_line(r.stdout)["heads_in_order"] is True
+
+
+def test_head_sharded_mode_needs_a_divisor_of_the_kv_heads():
+    r = _run("--gpus", "3", "--launcher-check", "--parallelism", "heads")
+    assert r.returncode != 0 and "divide the 8 KV heads" in r.stderr
+
+
+def test_scaling_label_follows_the_workload():
+    """fixed total work divided over the ranks is strong scaling, fixed per-GPU work is weak"""
+    src = open(BENCH).read()
+    assert 'res["scaling"] = "strong" if (heads_mode or workload == "long") else "weak"' in src
+    assert 'scaling=res.get("scaling", "weak")' in src
+
+
 def test_a_failing_rank_fails_the_run():
     r = _run("--gpus", "2", "--launcher-check", "--launcher-check-fail-rank", "1")
     assert r.returncode != 0

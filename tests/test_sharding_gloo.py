@@ -79,3 +79,59 @@ def test_ranges_partition_exactly():
     assert nv.sharding.q_head_range(32, 8, 4, 3) == (24, 32)
     with pytest.raises(ValueError):
         nv.sharding.kv_head_range(8, 3, 0)
+
+
+def test_prefix_sharding_colocates_shared_first_blocks():
+    """sequences that share their first block (the key allocate_with_prefix looks up,
+    block_manager.rs:337-347) go to ONE rank, so the shared blocks exist on one GPU only: with a
+    BlockManager per rank, the placement costs exactly one copy of the prefix in the whole job,
+    against one per rank under contiguous ranges."""
+    sh = nv.sharding
+    bs, world = 16, 4
+    prompts = []
+    for fam in range(6):                                  # six prompt families of 5 sequences each
+        head = np.arange(fam * 100, fam * 100 + 2 * bs, dtype=np.uint32)
+        for j in range(5):
+            prompts.append(np.concatenate([head, np.arange(7 + j, dtype=np.uint32) + 9000 * (j + 1)]))
+    prompts.append(np.arange(5, dtype=np.uint32))         # shorter than a block: no hash
+    rng = np.random.default_rng(0)
+    order = rng.permutation(len(prompts))
+    prompts = [prompts[i] for i in order]
+    hashes = [nv.hash_token_block(p[:bs], None) if len(p) >= bs else None for p in prompts]
+
+    ranks = [sh.shard_by_prefix(h, world, seq_id=i) for i, h in enumerate(hashes)]
+    assert all(0 <= r < world for r in ranks)
+    by_hash = {}
+    for h, r in zip(hashes, ranks):
+        if h is not None:
+            by_hash.setdefault(h, set()).add(r)
+    assert len(by_hash) == 6 and all(len(v) == 1 for v in by_hash.values())
+    assert sh.shard_by_prefix(None, world, seq_id=9) == 1
+
+    parts = sh.partition_by_prefix(hashes, world)
+    assert sorted(i for p in parts for i in p) == list(range(len(prompts)))
+    for h in by_hash:
+        owners = {r for r, p in enumerate(parts) for i in p if hashes[i] == h}
+        assert len(owners) == 1
+    sizes = [len(p) for p in parts]
+    assert max(sizes) - min(sizes) <= 5                   # at most the largest group apart
+    assert parts == sh.partition_by_prefix(hashes, world)  # deterministic
+
+    def prefix_block_copies(assignment):
+        """blocks spent on the two shared head blocks over all ranks, one BlockManager per rank"""
+        copies = 0
+        for idxs in assignment:
+            mgr = nv.BlockManager(4096, bs)
+            for i in idxs:
+                p, parent = prompts[i], None
+                for b in range(len(p) // bs):
+                    parent = nv.hash_token_block(p[b * bs:(b + 1) * bs], parent)
+                    _, cached = mgr.allocate_with_prefix(parent)
+                    copies += 0 if cached else 1
+        return copies
+
+    contiguous = [list(range(*sh.sequence_range(len(prompts), world, r))) for r in range(world)]
+    assert prefix_block_copies(parts) == 6 * 2            # every family's two blocks exactly once
+    assert prefix_block_copies(contiguous) > 6 * 2
+    with pytest.raises(ValueError):
+        sh.shard_by_prefix(1, 0)
