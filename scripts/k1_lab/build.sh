@@ -15,7 +15,7 @@ for spec in "$@"; do
   path=${rest%%:*}; extra=""
   if [[ "$rest" == *:* ]]; then extra=${rest#*:}; fi
   echo "LAB_VARIANT($name)" >> $OUT/variants.inc
-  /opt/rocm/bin/hipcc $FLAGS $extra -Dlaunch_flash_attn_mfma=launch_$name -Dflash_attn_mfma_supported=supported_$name -Dlaunch_flash_attn_paged=launch_paged_$name -Dflash_attn_paged_supported=paged_supported_$name -Dflash_attn_paged_workspace_bytes=paged_ws_$name \
+  /opt/rocm/bin/hipcc $FLAGS $extra -Dlaunch_flash_attn_pp=launch_$name -Dflash_attn_pp_supported=supported_$name -Dlaunch_flash_attn_pp_paged_stub=launch_paged_$name -Dlaunch_flash_attn_mfma=launch_$name -Dflash_attn_mfma_supported=supported_$name -Dlaunch_flash_attn_paged=launch_paged_$name -Dflash_attn_paged_supported=paged_supported_$name -Dflash_attn_paged_workspace_bytes=paged_ws_$name \
       -x hip -c $path -o $OUT/$name.o &
   pids="$pids $!"
   OBJS="$OBJS $OUT/$name.o"
