@@ -471,7 +471,10 @@ def run_prefill(args, nv, dev, rank, world, steps, warmup, cpu=True):
     return res
 
 
-def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
+def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens, order="random"):
+    """K4 over `num_tokens` new rows.  order: "random" = every row to a random slot of the pool (the
+    worst case, and the headline); "ascending_blocks" = whole blocks in ascending id order with gaps,
+    what a prefill gets from a fresh free list."""
     Hkv, D, bs, nb = 8, 128, 16, 40960
     g = torch.Generator(device="cpu").manual_seed(6 + rank)
     nbuf = 4                                   # rotate so the caches do not serve the re-reads
@@ -479,7 +482,11 @@ def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
              torch.randn((num_tokens, Hkv, D), generator=g).to(dev, torch.bfloat16)) for _ in range(nbuf)]
     kc = torch.zeros((nb, bs, Hkv, D), dtype=torch.bfloat16, device=dev)
     vc = torch.zeros_like(kc)
-    slots = torch.randperm(nb * bs, generator=g)[:num_tokens].to(dev)
+    if order == "random":
+        slots = torch.randperm(nb * bs, generator=g)[:num_tokens].to(dev)
+    else:
+        blk = torch.sort(torch.randperm(nb, generator=g)[:(num_tokens + bs - 1) // bs]).values
+        slots = (blk[:, None] * bs + torch.arange(bs)[None, :]).reshape(-1)[:num_tokens].contiguous().to(dev)
 
     def step(i):
         key, val = bufs[i % nbuf]
@@ -489,7 +496,8 @@ def run_kvwrite(args, nv, dev, rank, world, steps, warmup, num_tokens):
     bytes_moved = num_tokens * (2 * Hkv * D * 2) * 2 + num_tokens * 8   # read + written + slots
     return dict(metric="kv_write_GBps", unit="GB/s", value=world * bytes_moved * steps / wall / 1e9,
                 ms_per_step=wall / steps * 1e3,
-                config=dict(workload="reshape_and_cache, %d tokens, 8 KV heads, hd128, bf16" % num_tokens,
+                config=dict(workload="reshape_and_cache, %d tokens, 8 KV heads, hd128, bf16, %s slots"
+                                     % (num_tokens, order),
                             algorithmic_bytes_per_step_per_gpu=bytes_moved),
                 roofline=dict(bound="hbm", achieved=bytes_moved / (ev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
                               unit="GB/s", frac=bytes_moved / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -591,6 +599,9 @@ def main(argv=None):
             w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, n)
             also["kv_write_%d" % n] = dict(value=w["value"], unit="GB/s", ms_per_step=w["ms_per_step"],
                                            frac=w["roofline"]["frac"])
+        w = run_kvwrite(args, nv, dev, rank, world, args.steps, args.warmup, 32768, order="ascending_blocks")
+        also["kv_write_32768_ascending_blocks"] = dict(value=w["value"], unit="GB/s",
+                                                       ms_per_step=w["ms_per_step"], frac=w["roofline"]["frac"])
         for n in (256, 32768):
             w = run_producer(args, nv, dev, rank, world, args.steps, args.warmup, n)
             also["qk_norm_rope_cache_%d" % n] = dict(value=w["value"], unit="GB/s",

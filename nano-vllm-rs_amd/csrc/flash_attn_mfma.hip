@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -49,6 +50,7 @@
 // design) must never reach the product library: they compile only when the lab says who it is.
 #if !defined(NVLLM_K1_LAB) &&                                                                      \
     (defined(NVLLM_K1_STAMPS) || defined(K1_FINE) || defined(K1_RT) || defined(K1_ABL_NOVALU) ||   \
+     defined(K1_DEV_ONLY_CHAIN) ||                                                                 \
      defined(K1_ABL_NOSTAGE) || defined(K1_ABL_NOBRANCH) || defined(K1_ABL_SKIP_KINDS) ||          \
      defined(K1_DBG_VALU_L) || defined(K1_DBG_FENCE))
 #error "K1 lab switch (NVLLM_K1_STAMPS / K1_ABL_* / K1_DBG_*) defined without NVLLM_K1_LAB: not a product build"
@@ -81,7 +83,8 @@ constexpr int kVRing = 3, kKRing = 3;
 constexpr int kKBase = kVRing * kVTile;
 constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 98,304 B
 constexpr int kORow = 272, kOStage = 32 * kORow;  // epilogue: O rows of a block, padded
-static_assert(2 * kWaves * kOStage <= kLdsBytes, "O staging must fit the K/V rings");
+constexpr int kArgsCopy = 128;                    // CHAIN: a wave's copy of the kernel arguments (KArgs)
+static_assert(kLdsBytes + kWaves * (kOStage + kArgsCopy) <= 160 * 1024, "rings + O staging must fit the CU's LDS");
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
 
 // Diagnostic build only (scripts/k1_lab, -DNVLLM_K1_STAMPS): per-wave cycle sums of the loop's
@@ -245,6 +248,13 @@ __device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float &x, float &y, u32x4 &z) {
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
 }
+// An opaque copy: what is computed from it cannot be hoisted out of the loop it sits in (hipcc
+// otherwise keeps every loop-invariant lane constant of the item loop's prologue and epilogue
+// live across the steps, where no register is free)
+__device__ __forceinline__ int fresh(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
 // fmaxf on MFMA outputs makes hipcc canonicalise every input first (v_max_f32 x, x, x): the running
@@ -379,17 +389,40 @@ constexpr DealPlan make_deal_plan(int mode) {
 // (bf16 O; f32 m, l) in the workspace; flash_attn_ksplit_merge_kernel combines the P parts.
 constexpr int kSplitSlotBytes = 2 * kQTile * kD * 2 + 2 * kQTile * 2 * 4;  // 256 rows: O + (m, l)
 
-template <bool CAUSAL, bool PAGED, bool KSPLIT>
+// The kernel's arguments as they lie in the kernarg segment.  CHAIN reads what an item's set-up and
+// epilogue need again, item by item: held in scalar registers across the steps (where the plain
+// kernel has long forgotten them) they cost ~70 spilled SGPRs and, with those, vector registers the
+// steps do not have.  Not from the kernarg segment itself (host memory: 2500 cycles a read, measured)
+// but from a copy every wave puts into LDS when it starts.
+struct KArgs {
+    const __bf16 *q, *k, *v;
+    __bf16 *o;
+    float *lse;
+    int Sq, Skv, Hq, Hkv, num_q_tiles, pair_adjacent;
+    float scale_log2e;
+    const int32_t *block_tables, *context_lens;
+    int max_blocks_per_seq;
+    unsigned num_cache_blocks;
+    unsigned char *split_ws;
+    int pack_shift, num_seqs, chain_items, chain_gx;
+};
+static_assert(offsetof(KArgs, scale_log2e) == 64 && offsetof(KArgs, block_tables) == 72 &&
+                  offsetof(KArgs, split_ws) == 96 && offsetof(KArgs, chain_gx) == 116 && sizeof(KArgs) <= 128,
+              "KArgs mirrors the kernel's parameter list");
+typedef const __attribute__((address_space(4))) KArgs *KArgsPtr;
+
+template <bool CAUSAL, bool PAGED, bool KSPLIT, bool CHAIN>
 __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
-    __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv, int Hq, int Hkv,
-    int num_q_tiles, int pair_adjacent, float scale_log2e,
+    __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv_arg, int Hq, int Hkv,
+    int num_q_tiles_arg, int pair_adjacent, float scale_log2e,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ context_lens,
     int max_blocks_per_seq, unsigned num_cache_blocks, unsigned char *__restrict__ split_ws,
-    int pack_shift, int num_seqs) {
+    int pack_shift, int num_seqs, int chain_items, int chain_gx) {
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    static_assert(!CHAIN || !KSPLIT, "a key-split launch has fewer workgroups than CUs: nothing to chain");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes + kWaves * kOStage + kWaves * kArgsCopy];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,8 +444,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // short chunks need (T = 64 at 32Q/8KV: one full workgroup per kv head, not four with a quarter
     // of their rows live).  A 32-row block spans 32 / gp positions, so its diagonal still lies in
     // one 64-key tile.  gsh = 0: a row is a position, as in the dense kernel.
-    const int gsh = PAGED ? pack_shift : 0;
-    const int gp = 1 << gsh;
     // blockIdx.x = kvh + Hkv * (hg + Gq * J): kv head fastest; Gq head groups of gp heads per kv head;
     // blockIdx.y = batch element.  PAGED: blockIdx.x = kvh + Hkv * (hg + Gq * (b + num_seqs * J)), the
     // pair index slowest over the WHOLE grid: a paged grid is sized for the worst alignment of the
@@ -422,128 +453,295 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // index, live and empty workgroups alternated and all the live ones queued on half of the
     // engines (T = 64 at 32Q/8KV: 128 of 256 CUs busy, measured with wall-clock stamps); with J
     // slowest the empty ones come last and cost nothing.
-    const int G = Hq / Hkv;
-    const int Gq = G >> gsh;
-    int bid = blockIdx.x;
-    const int kvh = bid % Hkv;
-    bid /= Hkv;
-    const int hg = bid % Gq;
-    bid /= Gq;
-    const int J = PAGED ? bid / num_seqs : bid;
-    const int hu = kvh + Hkv * hg;                          // unit (kv head, head group)
-    const int hq = kvh * G + hg * gp + (c & (gp - 1));      // this lane's query head
-    const int b = PAGED ? bid % num_seqs : blockIdx.y;
+    // CHAIN: a workgroup keeps its unit and pair index and works through several batch elements
+    // (sequences) one after the other; it requests an item's Q rows and first K/V tiles before it
+    // writes the finished item's O (see the loop at the bottom).
+    // the arguments an item's set-up / epilogue works with.  CHAIN reads them afresh from the wave's
+    // copy in LDS (see KArgs; dword i in lane i, then one v_readlane per field used)
+    constexpr bool kArgsInLds = CHAIN && !PAGED;
+    if constexpr (kArgsInLds) {
+        typedef const __attribute__((address_space(4))) unsigned *KWords;
+        const unsigned w = ((KWords)__builtin_amdgcn_kernarg_segment_ptr())[lane & 31];
+        *reinterpret_cast<unsigned *>(lds + kLdsBytes + kWaves * kOStage + wave * kArgsCopy + (lane & 31) * 4) = w;
+    }
+    auto args = [&]() -> KArgs {
+        if constexpr (CHAIN && !kArgsInLds) {
+            // (the paged kernel: with its arguments born in vector registers hipcc builds the block
+            // descriptors there too, which the DMA statements' "s" operands do not survive; it reads
+            // the kernarg segment, once per item)
+            KArgsPtr p = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(p));
+            return KArgs{p->q, p->k, p->v, p->o, p->lse, p->Sq, p->Skv, p->Hq, p->Hkv, p->num_q_tiles,
+                         p->pair_adjacent, p->scale_log2e, p->block_tables, p->context_lens,
+                         p->max_blocks_per_seq, p->num_cache_blocks, p->split_ws, p->pack_shift, p->num_seqs,
+                         p->chain_items, p->chain_gx};
+        } else if constexpr (CHAIN) {
+            const int l = fresh(tid) & 31;
+            const unsigned w = *reinterpret_cast<const unsigned *>(lds + kLdsBytes + kWaves * kOStage + wave * kArgsCopy + l * 4);
+            auto S = [&](int i) { return (unsigned)__builtin_amdgcn_readlane((int)w, i); };
+            auto P = [&](int i) { return (unsigned long long)S(i) | ((unsigned long long)S(i + 1) << 32); };
+            return KArgs{(const __bf16 *)P(0), (const __bf16 *)P(2), (const __bf16 *)P(4), (__bf16 *)P(6), (float *)P(8),
+                         (int)S(10), (int)S(11), (int)S(12), (int)S(13), (int)S(14), (int)S(15),
+                         __builtin_bit_cast(float, S(16)), (const int32_t *)P(18), (const int32_t *)P(20), (int)S(22),
+                         S(23), (unsigned char *)P(24), (int)S(26), (int)S(27), (int)S(28), (int)S(29)};
+        } else {
+            return KArgs{q, k, v, o, lse, Sq, Skv_arg, Hq, Hkv, num_q_tiles_arg, pair_adjacent, scale_log2e,
+                         block_tables, context_lens, max_blocks_per_seq, num_cache_blocks, split_ws, pack_shift,
+                         num_seqs, chain_items, chain_gx};
+        }
+    };
+    // ---- the item and everything that follows from it (set by setup(), read by everything below)
+    int kvh = 0, hg = 0, J = 0, hu = 0, hq = 0, b = 0;
+    int Skv = Skv_arg, num_q_tiles = num_q_tiles_arg;
     // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
     // the tiling starts) and the dead rows in front of the first block (pos_shift)
     int kv_off = 0, pos_base = 0, pos_shift = 0;
-    // PAGED, no key split: the ids of the wave's blocks in key tiles 0..3 depend on nothing but the
-    // sequence, so they are requested here, beside the context length, not behind it (one scalar
-    // cache miss less in the prologue's chain length -> ids -> tiles)
     unsigned early_id[4] = {0u, 0u, 0u, 0u};
-    if constexpr (PAGED && !KSPLIT) {
-        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int bi = 4 * i + w;
-            bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
-            early_id[i] = (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
-        }
-    }
-    if constexpr (PAGED) {
-        Skv = context_lens[b];
-        const int cap = max_blocks_per_seq * 16;
-        Skv = Skv < 0 ? 0 : (Skv > cap ? cap : Skv);
-        kv_off = Skv - Sq;
-        pos_shift = kv_off & 31;
-        pos_base = kv_off - pos_shift;
-        num_q_tiles = (((Sq + pos_shift) << gsh) + kQTile - 1) / kQTile;
-        if (J >= (num_q_tiles + 1) / 2) return;  // the grid is sized for pos_shift = 31
-    }
-    // Which two query tiles this workgroup owns.  Balanced pairing (J, NT-1-J) gives every
-    // workgroup the same causal work -- the choice when the grid is about one workgroup per CU.
-    // Adjacent pairing (2J, 2J+1), heaviest pairs first, keeps both blocks on the same key
-    // range for almost the whole walk, so nearly every fragment read feeds two MFMAs -- the
-    // choice when there are many workgroups per CU and the tail evens out by itself.
-    int tile_long = num_q_tiles - 1 - J, tile_short = J;
-    if (pair_adjacent) {
-        const int pairs = (num_q_tiles + 1) / 2;
-        const int jr = CAUSAL ? pairs - 1 - J : J;
-        tile_short = 2 * jr;
-        tile_long = 2 * jr + 1 < num_q_tiles ? 2 * jr + 1 : 2 * jr;
-    }
-
-    const int nkv = (Skv + kKV - 1) / kKV;
-    // r0 = first row of a block, counted from pos_base - kv_off (= row 0 unless PAGED)
-    auto tiles_for = [&](int r0) {
-        if ((r0 >> gsh) - pos_shift >= Sq) return 0;
-        int n = nkv;
-        if (CAUSAL) {
-            const int last = ((r0 + 31) >> gsh) + pos_base;  // last position of the block
-            if (last < 0) return 0;
-            const int d = last / kKV + 1;
-            n = d < n ? d : n;
-        }
-        return n;
-    };
-    int rowA0 = tile_long * kQTile + 32 * wave;
-    int rowB0 = tile_short * kQTile + 32 * wave;
-    int nA = tiles_for(rowA0);
-    int nB = (tile_short != tile_long) ? tiles_for(rowB0) : 0;
-    if (nB > nA) {  // block A is the one with the longer key range
-        int x = rowA0; rowA0 = rowB0; rowB0 = x;
-        x = nA; nA = nB; nB = x;
-    }
-    // key tiles the workgroup walks (same in every wave)
-    int nsteps = nkv;
-    if (CAUSAL) {
-        int last = ((tile_long * kQTile + kQTile - 1) >> gsh) + pos_base;
-        last = last < Sq - 1 + kv_off ? last : Sq - 1 + kv_off;
-        const int d = last < 0 ? 0 : last / kKV + 1;
-        nsteps = d < nsteps ? d : nsteps;
-    }
+    int tile_long = 0, tile_short = 0, nA = 0, nB = 0, nsteps = 0;
     int tile0 = 0;  // KSPLIT: first key tile of this part
-    if constexpr (KSPLIT) {
-        const int parts = (int)gridDim.z, part = (int)blockIdx.z;
-        tile0 = (int)((long long)part * nsteps / parts);
-        const int k1 = (int)((long long)(part + 1) * nsteps / parts);
-        nA = (nA < k1 ? nA : k1) - tile0;
-        nB = (nB < k1 ? nB : k1) - tile0;
-        nA = nA > 0 ? nA : 0;
-        nB = nB > 0 ? nB : 0;
-        nsteps = k1 - tile0;
-    }
-    // a block with rows to store may have no keys at all (PAGED, context shorter than the chunk)
-    const bool liveA = (rowA0 >> gsh) - pos_shift < Sq;
-    const bool liveB = tile_short != tile_long && (rowB0 >> gsh) - pos_shift < Sq;
-
+    bool liveA = false, liveB = false;
     Block A, B;  // qrow = the lane's query POSITION (= row unless PAGED)
-    A.qrow = ((rowA0 + c) >> gsh) + pos_base;
-    B.qrow = ((rowB0 + c) >> gsh) + pos_base;
-    A.r0 = rowA0;
-    B.r0 = rowB0;
+    // Q goes to the accumulator file in two phases so that its HBM latency (about 3000 cycles on
+    // a first touch) overlaps the first K/V tile's fetch (and, CHAIN, the epilogue of the item
+    // before): the loads are issued by setup(), the Q^T registers are written in the prologue.
+    u32x4 qa[8], qb[8];
     // reserves a[0:223] in the kernel descriptor; every later statement names them literally
     asm volatile("" ::: K1_AGPRS);
     constexpr ic<0> kA{};
     constexpr ic<1> kB{};
-    // Q goes to the accumulator file in two phases so that its HBM latency (about 3000 cycles on
-    // a first touch) overlaps the zeroing of O / l and the first K/V tile's fetch: the loads are
-    // issued here, the Q^T registers are written in the prologue after tile 0's loads are out.
-    u32x4 qa[8], qb[8];
-    auto issue_q = [&](Block &blk, auto bt, bool live, u32x4 (&x)[8]) {
-        constexpr int bi = decltype(bt)::value;
-        const int row = blk.qrow - kv_off;
-        const bool ok = live && row >= 0 && row < Sq;
-        const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? row : 0)) * Hq + hq) * kD + 8 * h;
+
+    // ---- staging: thread handles rows st_row0 + 16i (i = 0..3), 16-byte chunk st_ch, of the K and
+    // of the V tile: 8 pieces per tile and thread (0..3 = K rows, 4..7 = V rows).  Buffer loads
+    // over this (batch, kv head)'s rows: the tile offset rides in the scalar offset (no address
+    // arithmetic per load) and rows past Skv read as zero (those keys are masked out of S in the
+    // block's last tile, so their P is exactly 0).
+    const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
+    // PAGED: a wave's four pieces of a tile are the 16 rows of ONE cache block (block 4 tile + wave
+    // of the sequence), so the block is addressed through the buffer descriptor itself: base = cache
+    // + id * block bytes + the kv head's 256 bytes (64-bit scalar arithmetic, any cache size),
+    // num_records = what is left of the block from there, and a lane's 32-bit offset (a lane constant
+    // per piece) stays inside the block.  The id is a scalar, read through the scalar cache three
+    // tiles ahead.  An id outside the pool gets num_records = 0 and reads as zero, like a row past Skv
+    // of a dense launch; rows of V past the context get an offset past the block (true zeros), K needs
+    // no such care (those scores are masked).
+    const unsigned pg_block_bytes = (unsigned)(16 * Hkv * kD * 2);
+    // Piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
+    // instruction: lane L writes LDS bytes [16 L, 16 L + 16) of the piece's 1 KiB, i.e. position
+    // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
+    unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
+    u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};  // dense: this item's K / V rows
+    unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
+    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // id of the wave's block in tiles t+1, t+2, t+3
+    unsigned long long pg_kbase = 0, pg_vbase = 0;  // PAGED: the caches from this item's kv head on
+    unsigned pg_nrec = 0;                           // ... and what is left of a block from there
+    constexpr unsigned kPgOutOfBlock = 0x40000000u;  // an offset no block reaches (Hkv < 2^15)
+    {
+        const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
+        if constexpr (PAGED) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            x[ks] = u32x4{0u, 0u, 0u, 0u};
-            if (ok) x[ks] = *reinterpret_cast<const u32x4 *>(qp + 16 * ks);
+            for (int j = 0; j < 4; ++j) {
+                const unsigned r = 4u * j + rin;
+                dma_pk[j] = r * row_bytes + 16u * (pos ^ (r & 15u));
+                dma_pv[j] = r * row_bytes + 16u * (pos ^ (4u * rin));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
+            dma_vv = rin * row_bytes + 16u * (pos ^ (4u * rin));
         }
+    }
+
+    // CHAIN: the workgroup's unit (kv head, head group), pair index and first batch element, decoded
+    // once -- blockIdx.x = unit + Hu * (c + chain_gx * J) with chain_gx chains per (unit, J), J slowest
+    // (see above); the chain's items are batch elements c, c + chain_gx, ... < chain_items.  An item
+    // then costs no integer division (a dozen of them were 3 us of scalar latency per item).
+    int ch_kvh = 0, ch_hg = 0, ch_J = 0, ch_b = 0;
+    // PAGED: what the next item's set-up waits for longest -- its context length and the ids of its
+    // first blocks -- requested one store earlier (pf_b = the sequence they belong to, -1 none)
+    int pf_b = -1, pf_ctx = 0;
+    unsigned pf_id[4] = {0u, 0u, 0u, 0u};
+    if constexpr (CHAIN) {
+        const int gsh = PAGED ? pack_shift : 0, Gq = (Hq / Hkv) >> gsh, Hu = Hkv * Gq;
+        int bid = blockIdx.x;
+        const int u = bid % Hu;
+        bid /= Hu;
+        ch_b = bid % chain_gx;
+        ch_J = bid / chain_gx;
+        ch_kvh = u % Hkv;
+        ch_hg = u / Hkv;
+    }
+    // Takes up an item: geometry, the Q loads (into qa / qb), softmax state.  CHAIN: batch element
+    // `cb`, every other one with the pair index mirrored (`flip`: a heavy pair of tiles is followed by
+    // a light one).  false = the item has no rows (PAGED: the grid is sized for pos_shift = 31).
+    auto setup = [&](int cb, bool flip, const KArgs &ka) -> bool {
+        const int tid_f = CHAIN ? fresh(tid) : tid;
+        const int c = tid_f & 31, h = (tid_f >> 5) & 1;  // (shadow the kernel's: not hoistable)
+        const int Sq = ka.Sq, Hq = ka.Hq, Hkv = ka.Hkv, num_seqs = ka.num_seqs;
+        const int max_blocks_per_seq = ka.max_blocks_per_seq, pair_adjacent = ka.pair_adjacent;
+        const int gsh = PAGED ? ka.pack_shift : 0, gp = 1 << gsh, G = Hq / Hkv;
+        const int32_t *block_tables = ka.block_tables, *context_lens = ka.context_lens;
+        const __bf16 *q = ka.q, *k = ka.k, *v = ka.v;
+        const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
+        if constexpr (CHAIN) {
+            kvh = ch_kvh;
+            hg = ch_hg;
+            J = ch_J;
+            b = cb;
+            (void)num_seqs;
+        } else {
+            const int Gq = G >> gsh;
+            int bid = blockIdx.x;
+            kvh = bid % Hkv;
+            bid /= Hkv;
+            hg = bid % Gq;
+            bid /= Gq;
+            J = PAGED ? bid / num_seqs : bid;
+            b = PAGED ? bid % num_seqs : (int)blockIdx.y;
+        }
+        hu = kvh + Hkv * hg;                                        // unit (kv head, head group)
+        hq = kvh * G + hg * gp + (c & (gp - 1));         // this lane's query head
+        // PAGED, no key split: the ids of the wave's blocks in key tiles 0..3 depend on nothing but the
+        // sequence, so they are requested here, beside the context length, not behind it (one scalar
+        // cache miss less in the prologue's chain length -> ids -> tiles)
+        const bool prefetched = CHAIN && PAGED && pf_b == b;
+        if constexpr (PAGED && !KSPLIT) {
+            if (prefetched) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) early_id[i] = pf_id[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int bi = 4 * i + wave;
+                    bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
+                    early_id[i] = (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
+                }
+            }
+        }
+        if constexpr (!PAGED) {
+            Skv = ka.Skv;
+            num_q_tiles = ka.num_q_tiles;
+        }
+        if constexpr (PAGED) {
+            Skv = prefetched ? pf_ctx : context_lens[b];
+            const int cap = max_blocks_per_seq * 16;
+            Skv = Skv < 0 ? 0 : (Skv > cap ? cap : Skv);
+            kv_off = Skv - Sq;
+            pos_shift = kv_off & 31;
+            pos_base = kv_off - pos_shift;
+            num_q_tiles = (((Sq + pos_shift) << gsh) + kQTile - 1) / kQTile;
+            if (J >= (num_q_tiles + 1) / 2) return false;
+        }
+        // Which two query tiles this workgroup owns.  Balanced pairing (J, NT-1-J) gives every
+        // workgroup the same causal work -- the choice when the grid is about one workgroup per CU.
+        // Adjacent pairing (2J, 2J+1), heaviest pairs first, keeps both blocks on the same key
+        // range for almost the whole walk, so nearly every fragment read feeds two MFMAs -- the
+        // choice when there are many workgroups per CU and the tail evens out by itself.
+        if (CHAIN && flip) J = (num_q_tiles + 1) / 2 - 1 - J;
+        tile_long = num_q_tiles - 1 - J, tile_short = J;
+        if (pair_adjacent) {
+            const int pairs = (num_q_tiles + 1) / 2;
+            const int jr = CAUSAL ? pairs - 1 - J : J;
+            tile_short = 2 * jr;
+            tile_long = 2 * jr + 1 < num_q_tiles ? 2 * jr + 1 : 2 * jr;
+        }
+        const int nkv = (Skv + kKV - 1) / kKV;
+        // r0 = first row of a block, counted from pos_base - kv_off (= row 0 unless PAGED)
+        auto tiles_for = [&](int r0) {
+            if ((r0 >> gsh) - pos_shift >= Sq) return 0;
+            int n = nkv;
+            if (CAUSAL) {
+                const int last = ((r0 + 31) >> gsh) + pos_base;  // last position of the block
+                if (last < 0) return 0;
+                const int d = last / kKV + 1;
+                n = d < n ? d : n;
+            }
+            return n;
+        };
+        int rowA0 = tile_long * kQTile + 32 * wave;
+        int rowB0 = tile_short * kQTile + 32 * wave;
+        nA = tiles_for(rowA0);
+        nB = (tile_short != tile_long) ? tiles_for(rowB0) : 0;
+        if (nB > nA) {  // block A is the one with the longer key range
+            int x = rowA0; rowA0 = rowB0; rowB0 = x;
+            x = nA; nA = nB; nB = x;
+        }
+        // key tiles the workgroup walks (same in every wave)
+        nsteps = nkv;
+        if (CAUSAL) {
+            int last = ((tile_long * kQTile + kQTile - 1) >> gsh) + pos_base;
+            last = last < Sq - 1 + kv_off ? last : Sq - 1 + kv_off;
+            const int d = last < 0 ? 0 : last / kKV + 1;
+            nsteps = d < nsteps ? d : nsteps;
+        }
+        if constexpr (KSPLIT) {
+            const int parts = (int)gridDim.z, part = (int)blockIdx.z;
+            tile0 = (int)((long long)part * nsteps / parts);
+            const int k1 = (int)((long long)(part + 1) * nsteps / parts);
+            nA = (nA < k1 ? nA : k1) - tile0;
+            nB = (nB < k1 ? nB : k1) - tile0;
+            nA = nA > 0 ? nA : 0;
+            nB = nB > 0 ? nB : 0;
+            nsteps = k1 - tile0;
+        }
+        // a block with rows to store may have no keys at all (PAGED, context shorter than the chunk)
+        liveA = (rowA0 >> gsh) - pos_shift < Sq;
+        liveB = tile_short != tile_long && (rowB0 >> gsh) - pos_shift < Sq;
+        A.qrow = ((rowA0 + c) >> gsh) + pos_base;
+        B.qrow = ((rowB0 + c) >> gsh) + pos_base;
+        A.r0 = rowA0;
+        B.r0 = rowB0;
+        auto issue_q = [&](Block &blk, bool live, u32x4 (&x)[8]) {
+            const int row = blk.qrow - kv_off;
+            const bool ok = live && row >= 0 && row < Sq;
+            const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? row : 0)) * Hq + hq) * kD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                x[ks] = u32x4{0u, 0u, 0u, 0u};
+                if (ok) x[ks] = *reinterpret_cast<const u32x4 *>(qp + 16 * ks);
+            }
+            blk.m = -INFINITY;
+            blk.mc = 0.0f;
+            blk.thr = -INFINITY;
+        };
+        issue_q(A, liveA, qa);
+        issue_q(B, liveB, qb);
+        // (uni: these feed "s" operands of the DMA statements; CHAIN's arguments come out of LDS and
+        // hipcc would otherwise carry what is computed from them in vector registers)
+        auto uni = [](unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); };
+        auto uni64 = [&](unsigned long long x) {
+            return (unsigned long long)uni((unsigned)x) | ((unsigned long long)uni((unsigned)(x >> 32)) << 32);
+        };
+        if constexpr (PAGED) {
+            const unsigned head = (unsigned)kvh * (unsigned)(kD * 2);
+            pg_kbase = uni64((unsigned long long)k + head);
+            pg_vbase = uni64((unsigned long long)v + head);
+            pg_nrec = uni(pg_block_bytes - head);
+        } else {
+            const unsigned kv_bytes = (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
+            const int64_t head_off = ((int64_t)b * Skv * Hkv + kvh) * kD;
+            const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
+            dma_krs = u32x4{uni((unsigned)ka), uni((unsigned)(ka >> 32) & 0xffffu), uni(kv_bytes), 0x00020000u};
+            dma_vrs = u32x4{uni((unsigned)va), uni((unsigned)(va >> 32) & 0xffffu), uni(kv_bytes), 0x00020000u};
+        }
+        return true;
+    };
+    auto prefetch_scalars = [&](int cb, const KArgs &ka) {
+        if constexpr (CHAIN && PAGED) {
+            pf_b = cb;
+            pf_ctx = ka.context_lens[cb];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int bi = 4 * i + wave;
+                bi = bi < ka.max_blocks_per_seq ? bi : ka.max_blocks_per_seq - 1;
+                pf_id[i] = (unsigned)ka.block_tables[(int64_t)cb * ka.max_blocks_per_seq + bi];
+            }
+        }
+    };
+    // the accumulators of a block start at zero (O, row sums)
+    auto zero_acc = [&](auto bt) {
+        constexpr int bi = decltype(bt)::value;
         static_for<64>([&](auto R) { agpr_write<64 * bi + decltype(R)::value>(0u); });
         static_for<16>([&](auto R) { agpr_write<192 + 16 * bi + decltype(R)::value>(0u); });
-        blk.m = -INFINITY;
-        blk.mc = 0.0f;
-        blk.thr = -INFINITY;
     };
     auto commit_q = [&](auto bt, const u32x4 (&x)[8]) {
         constexpr int bi = decltype(bt)::value;
@@ -552,90 +750,54 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             agpr_write<128 + 32 * bi + r>(x[r >> 2][r & 3]);
         });
     };
-    issue_q(A, kA, liveA, qa);
-    issue_q(B, kB, liveB, qb);
-
-    // ---- staging: thread handles rows st_row0 + 16i (i = 0..3), 16-byte chunk st_ch, of the K and
-    // of the V tile: 8 pieces per tile and thread (0..3 = K rows, 4..7 = V rows).  Buffer loads
-    // over this (batch, kv head)'s rows: the tile offset rides in the scalar offset (no address
-    // arithmetic per load) and rows past Skv read as zero (those keys are masked out of S in the
-    // block's last tile, so their P is exactly 0).
-    const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
-    const unsigned kv_bytes = PAGED ? 0u : (unsigned)(Skv - 1) * row_bytes + (unsigned)(kD * 2);
-    const int64_t head_off = PAGED ? 0 : ((int64_t)b * Skv * Hkv + kvh) * kD;
-    // PAGED: a wave's four pieces of a tile are the 16 rows of ONE cache block, so the block is
-    // addressed through the buffer descriptor itself: base = cache + id * block bytes (64-bit
-    // scalar arithmetic, any cache size), num_records = the block's bytes, and a lane's 32-bit
-    // offset stays inside the block.  An id outside the pool gets num_records = 0 and reads as
-    // zero, like a row past Skv of a dense launch.
-    const unsigned pg_block_bytes = (unsigned)(16 * Hkv * kD * 2);
-    // Piece j of a tile = rows 16 wave + 4 (j & 3) .. + 3 (j < 4 of K, else of V), one
-    // instruction: lane L writes LDS bytes [16 L, 16 L + 16) of the piece's 1 KiB, i.e. position
-    // L & 15 of row L >> 4, and fetches the chunk that the swizzle puts there
-    unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
-    u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};
-    // PAGED: a wave's four pieces of a tile are the 16 rows of ONE block of the sequence (block
-    // 4 tile + wave), so its id is a scalar (read through the scalar cache, three tiles ahead) and a
-    // lane's byte offset inside the block is a lane constant per piece; rows of V past the context
-    // get an offset past the block (true zeros), K needs no such care (those scores are masked)
-    unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
-    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // id of the wave's block in tiles t+1, t+2, t+3
-    const unsigned long long pg_kbase = (unsigned long long)k, pg_vbase = (unsigned long long)v;
-    constexpr unsigned kPgOutOfBlock = 0x40000000u;  // an offset no block reaches (Hkv < 2^15)
-    {
-        const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
-        const unsigned long long ka = (unsigned long long)(k + head_off), va = (unsigned long long)(v + head_off);
-        if constexpr (PAGED) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned r = 4u * j + rin;
-                dma_pk[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 256u + 16u * (pos ^ (r & 15u));
-                dma_pv[j] = (r * (unsigned)Hkv + (unsigned)kvh) * 256u + 16u * (pos ^ (4u * rin));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dma_kv[j] = rin * row_bytes + 16u * (pos ^ ((4u * j + rin) & 15u));
-            dma_vv = rin * row_bytes + 16u * (pos ^ (4u * rin));
-            dma_krs = u32x4{(unsigned)ka, (unsigned)(ka >> 32) & 0xffffu, kv_bytes, 0x00020000u};
-            dma_vrs = u32x4{(unsigned)va, (unsigned)(va >> 32) & 0xffffu, kv_bytes, 0x00020000u};
-        }
-    }
     // PAGED: id of the block this wave fetches in key tile `tile` (clamped into the table row)
     auto dma_id = [&](int tile) -> unsigned {
         int bi = 4 * (tile + tile0) + wave;
         bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
         return (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
     };
-    // PAGED: descriptor of block `id` of a cache (all scalar: the id came through the scalar cache)
+    // PAGED: descriptor of this kv head's rows in block `id` of a cache (all scalar: the id came
+    // through the scalar cache)
     auto pg_desc = [&](unsigned long long base, unsigned id) -> u32x4 {
+        // (under register pressure hipcc parks a prefetched id in a vector register and would build
+        // the descriptor there, which no "s" operand survives: the id is uniform, say so)
+        id = (unsigned)__builtin_amdgcn_readfirstlane((int)id);
         const unsigned long long a = base + (unsigned long long)id * pg_block_bytes;
-        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, id < num_cache_blocks ? pg_block_bytes : 0u,
-                     0x00020000u};
+        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, id < num_cache_blocks ? pg_nrec : 0u, 0x00020000u};
     };
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
-    auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u) {
+    // settle = the scalar operands may have just come back from a spill lane (v_readlane: a VALU
+    // write of an SGPR, which a buffer instruction may read only 5 wait states later; hipcc does not
+    // look into the asm statement): one s_nop 4 between.  For the pieces issued outside the
+    // hand-scheduled bodies, whose operands are long in place (scripts/k1_lab/check_asm.py audits both).
+    auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u, bool settle = false) {
         const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)(j & 3);
-        const unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
-        const unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + r0 * 256u;
+        unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
+        unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + r0 * 256u;
         if constexpr (PAGED) {
+            u32x4 rs = pg_desc(j < 4 ? pg_kbase : pg_vbase, sid);
+            if (settle) asm volatile("s_nop 4" : "+s"(dst));
             if (j < 4) {
-                const u32x4 rs = pg_desc(pg_kbase, sid);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                              : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
             } else {
-                const u32x4 rs = pg_desc(pg_vbase, sid);
                 const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
                 const int r = 4 * (j & 3) + (lane >> 4);
                 const unsigned off = r < rows_left ? dma_pv[j & 3] : kPgOutOfBlock;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                              : : "s"(dst), "v"(off), "s"(rs) : "memory");
             }
-        } else if (j < 4)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         : : "s"(dst), "v"(dma_kv[j]), "s"(dma_krs), "s"(soff) : "memory");
-        else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         : : "s"(dst), "v"(dma_vv), "s"(dma_vrs), "s"(soff) : "memory");
+        } else {
+            u32x4 rs = j < 4 ? dma_krs : dma_vrs;
+            if (settle) asm volatile("s_nop 4" : "+s"(dst), "+s"(rs), "+s"(soff));
+            // the tile offset goes through a scalar move (which is also the wait state between the
+            // write of M0 and the load): under register pressure hipcc brings it back from a spill
+            // lane right in front of the statement, and a buffer instruction must not read an SGPR
+            // within 5 wait states of a VALU write; a scalar instruction may
+            unsigned so;
+            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, %4\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
+                         : "=&s"(so) : "s"(dst), "v"(j < 4 ? dma_kv[j] : dma_vv), "s"(rs), "s"(soff) : "memory");
+        }
     };
 
     // ---- LDS read addresses
@@ -681,7 +843,13 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #ifdef K1_DBG_VALU_L
     float dbg_l = 0.f;  // only valid for single-block (nB == 0) waves without rescale
 #endif
-    const float defer_raw = kDeferLog2 / scale_log2e;  // the rescale threshold in raw score units
+    // the rescale threshold in raw score units (only the rare path needs it: computed there, so that
+    // it does not hold a register -- CHAIN: or a scratch slot -- across the steps)
+    auto defer_raw = [&]() {
+        float sc = scale_log2e;
+        asm volatile("" : "+s"(sc));
+        return kDeferLog2 / sc;
+    };
     // ---- vector-ALU steps of one item's softmax, cut so that they can be dealt out between MFMAs
     // running max, step j of 16: sa pairs first (their MFMAs finished long ago), then sb pairs
     // (two alternating chains -- it.mx on even steps, it.xf, idle until the first element, on odd
@@ -739,7 +907,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const float alpha = fast_exp2((blk.m - m_safe) * scale_log2e);
         blk.m = m_new;
         blk.mc = m_safe * scale_log2e;
-        blk.thr = m_new + defer_raw;
+        blk.thr = m_new + defer_raw();
         mfma_fence();
         static_for<64>([&](auto R) { agpr_scale<64 * bi + decltype(R)::value>(alpha); });
         static_for<16>([&](auto R) { agpr_scale<192 + 16 * bi + decltype(R)::value>(alpha); });
@@ -933,9 +1101,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     };
     // mask of a block's last key tile: key < Skv and (causal) key <= query row
     auto mask = [&](Item &it, const Block &blk, int kv0) {
+        const int hh = CHAIN ? (fresh(tid) >> 5) & 1 : h;  // (CHAIN: keeps the 16 key offsets out of the item loop's live set)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const bool va = (key < Skv) && (!CAUSAL || key <= blk.qrow);
             const bool vb = (key + 32 < Skv) && (!CAUSAL || key + 32 <= blk.qrow);
             it.sa[r] = va ? it.sa[r] : -INFINITY;
@@ -949,6 +1118,49 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #pragma unroll
         for (int n = kFirst; n < kTicks; ++n) tick(it, blk, n);
         pv_plain(it, bt, vslot);
+    };
+    // ---- prologue of an item, first half: K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0, all
+    // requested together (PAGED: through the ids of the wave's blocks in tiles 0..3).  The rings must
+    // be free: nobody reads them any more (CHAIN: behind the barrier that ends the item before).
+    auto request_first_tiles = [&]() {
+        unsigned id0 = 0;
+        if constexpr (PAGED && !KSPLIT) {
+            id0 = early_id[0];
+            pg_s0 = early_id[1];
+            pg_s1 = early_id[2];
+            pg_s2 = early_id[3];
+        } else if constexpr (PAGED) {
+            id0 = dma_id(0);
+            pg_s0 = dma_id(1);
+            pg_s1 = dma_id(2);
+            pg_s2 = dma_id(3);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j, id0, true);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j, pg_s0, true);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j, id0, true);
+    };
+    // ... second half: accumulators zeroed, Q^T written, V slot 2 ("tile -1") zeroed, tiles landed
+    auto finish_prologue = [&]() {
+        zero_acc(kA);
+        zero_acc(kB);
+        commit_q(kA, qa);
+        commit_q(kB, qb);
+        if constexpr (CHAIN) {
+            // the staging registers are dead from here to the next item's set-up; hipcc cannot see
+            // that (the set-up sits behind a loop condition) and would carry them through the steps
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(qa[i]), "=v"(qb[i]));
+        }
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const int tid_f = CHAIN ? fresh(tid) : tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid_f) * 16) = z;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
     Item I0, I1;    // block A's two score register sets
     Item J0, J1;    // block B's
@@ -966,40 +1178,6 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         it.mx = -INFINITY;
         it.xf = -INFINITY; it.ya = 0.0f; it.yb = 0.0f;
     };
-    // ---- prologue: K(0) -> K slot 0, K(1) -> K slot 1, V(0) -> V slot 0, all requested together (and,
-    // PAGED, the ids of the wave's blocks in tiles 0..3); V slot 2 ("tile -1") zeroed
-    {
-        unsigned id0 = 0;
-        if constexpr (PAGED && !KSPLIT) {
-            id0 = early_id[0];
-            pg_s0 = early_id[1];
-            pg_s1 = early_id[2];
-            pg_s2 = early_id[3];
-        } else if constexpr (PAGED) {
-            id0 = dma_id(0);
-            pg_s0 = dma_id(1);
-            pg_s1 = dma_id(2);
-            pg_s2 = dma_id(3);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j, id0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j, pg_s0);
-#pragma unroll
-        for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j, id0);
-        commit_q(kA, qa);
-        commit_q(kB, qb);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid) * 16) = z;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    clear_item(I0);
-    clear_item(I1);
-    clear_item(J0);
-    clear_item(J1);
 
     int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
     int ks_cur = 0;                            // K ring slot of tile t
@@ -1128,69 +1306,40 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     constexpr std::false_type kInterior{};
     constexpr std::true_type kLastTile{};
 
-    // ---- phase 1: both blocks, alternating the two score register sets.  The (empty) pending items
-    // start in whichever set lets block B's last tile go from set 0 to set 1.  That tile is a
-    // pipelined step like the others, only masked; its item is then finished on its own (drain)
-    // during the following step, while its V tile is still in the ring.
-    if (nB > 0) {
-        if ((nB - 1) & 1) dual_step(I1, J1, I0, J0, kInterior, false);
-        while (t < nB - 1) {
-            dual_step(I0, J0, I1, J1, kInterior, false);
-            dual_step(I1, J1, I0, J0, kInterior, false);
-        }
-        const bool a_too = (t == nA - 1);
-        dual_step(I0, J0, I1, J1, kLastTile, a_too);
-        drain(J1, B, kB, vs_prev);
-        if (a_too) drain(I1, A, kA, vs_prev);
-        K1_STAMP(7);
-    }
-    // ---- phase 2: block A alone; its pending item is in set 1, the last tile goes from set 0 to
-    // set 1, so an even number of interior tiles in between needs the two sets exchanged (only
-    // happens when a key split cuts the walks; with no block B both sets are empty anyway)
-    if (t < nA) {
-        const int n2 = nA - 1 - t;
-        if (!(n2 & 1) && nB > 0) I0 = I1;  // set 0's old content is dead: its P.V is done
-        if (n2 & 1) single_step(I1, I0, kInterior);
-        while (t < nA - 1) {
-            single_step(I0, I1, kInterior);
-            single_step(I1, I0, kInterior);
-        }
-        single_step(I0, I1, kLastTile);
-        drain(I1, A, kA, vs_prev);
-        K1_STAMP(8);
-    }
-    // ---- steps this wave has no keys for (the workgroup's other waves do)
-    while (t < nsteps) {
-        stage_step();
-        K1_STAMP(9);
-        step_end();
-    }
-    // a drain after the last step still reads the V ring, which the epilogue reuses for O, and the
-    // pieces requested past the last tile must have landed before O is written over them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#ifdef K1_ABL_NOBRANCH
-    asm volatile("" ::"s"(abl_sticky));
-#endif
-
+    // ---- epilogue: O^T lane (c,h) holds O[qrow][32dt + 8i + 4h + (0..3)] in regs 4i..4i+3.
+    // What it needs of its item is saved in an Epi first: CHAIN takes up the next item before it runs.
+    struct Epi {
+        Block A, B;
+        int kv_off, pos_base, b, kvh, hg, hq, J, hu, tile_long, tile_short;
+        bool liveA, liveB;
+    };
 #ifdef NVLLM_K1_STAMPS
     float *lse_dbg = lse;
     lse = nullptr;
 #endif
-    // ---- epilogue: O^T lane (c,h) holds O[qrow][32dt + 8i + 4h + (0..3)] in regs 4i..4i+3
-    mfma_fence();
-    auto store = [&](Block &blk, auto bt, bool live) {
+    auto store = [&](const Epi &e, const Block &blk, auto bt, bool live, const KArgs &ka) {
         constexpr int bi = decltype(bt)::value;
+        const int tid_f = CHAIN ? fresh(tid) : tid;
+        const int lane = tid_f & 63, c = lane & 31, h = lane >> 5;  // (shadow the kernel's: not hoistable)
+        const int Sq = ka.Sq, Hq = ka.Hq, Hkv = ka.Hkv, num_seqs = ka.num_seqs;
+        const int gsh = PAGED ? ka.pack_shift : 0, gp = 1 << gsh, G = Hq / Hkv, Gq = G >> gsh;
+        __bf16 *o = ka.o;
+        unsigned char *split_ws = ka.split_ws;
+        (void)num_seqs; (void)Gq; (void)split_ws;
         float l = agpr_read<192 + 16 * bi>();
 #ifdef K1_DBG_VALU_L
-        if (bi == 0 && nB == 0) l = half_sum(dbg_l);
+        if (bi == 0 && e.tile_long == e.tile_short) l = half_sum(dbg_l);
 #endif
-        float ov[64];
-        static_for<64>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            ov[r] = agpr_read<64 * bi + r>();
-        });
-        const int row = blk.qrow - kv_off;
+        // four accumulator registers at a time, as they are packed: the whole block at once would
+        // need 64 registers beside the next item's Q rows (CHAIN)
+        auto acc4 = [&](auto DT, auto I, float (&a4)[4]) {
+            constexpr int r0 = 64 * bi + 16 * decltype(DT)::value + 4 * decltype(I)::value;
+            a4[0] = agpr_read<r0>();
+            a4[1] = agpr_read<r0 + 1>();
+            a4[2] = agpr_read<r0 + 2>();
+            a4[3] = agpr_read<r0 + 3>();
+        };
+        const int row = blk.qrow - e.kv_off;
         const float inv = l > 0.0f ? 1.0f / l : 0.0f;
         if constexpr (KSPLIT) {
             // this part's share of the rows: normalised O in bf16, then (m in the exp2 domain, l);
@@ -1198,22 +1347,21 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             if (live) {
                 const int vr = blk.r0 + c;  // (packed) row inside the sequence's tiling
                 const int tile = vr / kQTile;
-                const int ur = ((tile == tile_long && tile_long != tile_short) ? kQTile : 0) + (vr & (kQTile - 1));
+                const int ur = ((tile == e.tile_long && e.tile_long != e.tile_short) ? kQTile : 0) + (vr & (kQTile - 1));
                 const int Hu = Hkv * Gq;
                 const size_t pairs_max = gridDim.x / (unsigned)(Hu * num_seqs);
-                unsigned char *slot = split_ws + ((((size_t)b * Hu + hu) * pairs_max + J) * gridDim.z + blockIdx.z) *
+                unsigned char *slot = split_ws + ((((size_t)e.b * Hu + e.hu) * pairs_max + e.J) * gridDim.z + blockIdx.z) *
                                                      (size_t)kSplitSlotBytes;
                 __bf16 *op = reinterpret_cast<__bf16 *>(slot) + ur * kD + 4 * h;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float *a4 = ov + 16 * dt + 4 * i;
-                        u32x2 w;
-                        w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
-                        w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
-                        *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
-                    }
+                static_for<16>([&](auto X) {
+                    constexpr int dt = decltype(X)::value >> 2, i = decltype(X)::value & 3;
+                    float a4[4];
+                    acc4(ic<dt>{}, ic<i>{}, a4);
+                    u32x2 w;
+                    w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
+                    w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
+                    *reinterpret_cast<u32x2 *>(op + 32 * dt + 8 * i) = w;
+                });
                 if (h == 0) {
                     float *ml = reinterpret_cast<float *>(slot + 2 * kQTile * kD * 2) + 2 * ur;
                     ml[0] = blk.m * scale_log2e;
@@ -1221,42 +1369,139 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 }
             }
         } else {
-            // O goes through a wave-private LDS image (the K/V rings are free after the last
-            // barrier) and leaves as whole 256-byte rows, four per store instruction: stored
-            // straight from the accumulator layout every instruction would touch 32 rows, 16
-            // bytes each
-            unsigned char *stg = lds + (wave * 2 + bi) * kOStage;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float *a4 = ov + 16 * dt + 4 * i;
-                    u32x2 w;
-                    w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
-                    w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
-                    *reinterpret_cast<u32x2 *>(stg + c * kORow + (32 * dt + 8 * i + 4 * h) * 2) = w;
-                }
-            const int head0 = kvh * G + hg * gp;
+            // O goes through a wave-private LDS image (behind the K/V rings, which may already be
+            // taking the next item's tiles; block B reuses block A's image, a wave's LDS accesses
+            // keep their order) and leaves as whole 256-byte rows, four per store instruction:
+            // stored straight from the accumulator layout every instruction would touch 32 rows,
+            // 16 bytes each
+            unsigned char *stg = lds + kLdsBytes + wave * kOStage;
+            static_for<16>([&](auto X) {
+                constexpr int dt = decltype(X)::value >> 2, i = decltype(X)::value & 3;
+                float a4[4];
+                acc4(ic<dt>{}, ic<i>{}, a4);
+                u32x2 w;
+                w[0] = pack_bf16x2(a4[0] * inv, a4[1] * inv);
+                w[1] = pack_bf16x2(a4[2] * inv, a4[3] * inv);
+                *reinterpret_cast<u32x2 *>(stg + c * kORow + (32 * dt + 8 * i + 4 * h) * 2) = w;
+            });
+            const int head0 = e.kvh * G + e.hg * gp;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int ri = 4 * r + (lane >> 4);  // row of the block: position and head of the group
                 const u32x4 x = *reinterpret_cast<const u32x4 *>(stg + ri * kORow + (lane & 15) * 16);
-                const int orow = ((blk.r0 + ri) >> gsh) + pos_base - kv_off;
+                const int orow = ((blk.r0 + ri) >> gsh) + e.pos_base - e.kv_off;
                 const int ohead = head0 + (ri & (gp - 1));
                 if (live && orow >= 0 && orow < Sq)
-                    *reinterpret_cast<u32x4 *>(o + (((int64_t)b * Sq + orow) * Hq + ohead) * kD + (lane & 15) * 8) = x;
+                    *reinterpret_cast<u32x4 *>(o + (((int64_t)e.b * Sq + orow) * Hq + ohead) * kD + (lane & 15) * 8) = x;
             }
         }
         if (!KSPLIT && live && row >= 0 && row < Sq) {
             if (lse && h == 0)
-                lse[((int64_t)b * Hq + hq) * Sq + row] =
+                lse[((int64_t)e.b * Hq + e.hq) * Sq + row] =
                     blk.m * scale_log2e * 0.6931471805599453f + logf(l);
         }
     };
-    store(A, kA, liveA);
-    store(B, kB, liveB);
+
+    // ---- the items of this workgroup
+    int item = ch_b, nth = 0;  // CHAIN: batch element of the current item, its number in the chain
+    {
+        const KArgs ka = args();
+        bool have = false;
+        if constexpr (CHAIN) {
+            while (item < ka.chain_items && !(have = setup(item, !PAGED && (nth & 1), ka))) {
+                item += ka.chain_gx;
+                ++nth;
+            }
+        } else {
+            have = setup(0, false, ka);
+        }
+        if (!have) return;
+    }
+    request_first_tiles();
+    for (;;) {
+        finish_prologue();
+        clear_item(I0);
+        clear_item(I1);
+        clear_item(J0);
+        clear_item(J1);
+        vs_prev = 2, vs_cur = 0, vs_next = 1;
+        ks_cur = 0, ks_n1 = 1, ks_n2 = 2;
+        t = 0;
+        K1_STAMP(2);  // kernel start (or the epilogue's end) .. first step (Q load, first two tiles)
+        // ---- phase 1: both blocks, alternating the two score register sets.  The (empty) pending items
+        // start in whichever set lets block B's last tile go from set 0 to set 1.  That tile is a
+        // pipelined step like the others, only masked; its item is then finished on its own (drain)
+        // during the following step, while its V tile is still in the ring.
+        if (nB > 0) {
+            if ((nB - 1) & 1) dual_step(I1, J1, I0, J0, kInterior, false);
+            while (t < nB - 1) {
+                dual_step(I0, J0, I1, J1, kInterior, false);
+                dual_step(I1, J1, I0, J0, kInterior, false);
+            }
+            const bool a_too = (t == nA - 1);
+            dual_step(I0, J0, I1, J1, kLastTile, a_too);
+            drain(J1, B, kB, vs_prev);
+            if (a_too) drain(I1, A, kA, vs_prev);
+            K1_STAMP(7);
+        }
+        // ---- phase 2: block A alone; its pending item is in set 1, the last tile goes from set 0 to
+        // set 1, so an even number of interior tiles in between needs the two sets exchanged (only
+        // happens when a key split cuts the walks; with no block B both sets are empty anyway)
+        if (t < nA) {
+            const int n2 = nA - 1 - t;
+            if (!(n2 & 1) && nB > 0) I0 = I1;  // set 0's old content is dead: its P.V is done
+            if (n2 & 1) single_step(I1, I0, kInterior);
+            while (t < nA - 1) {
+                single_step(I0, I1, kInterior);
+                single_step(I1, I0, kInterior);
+            }
+            single_step(I0, I1, kLastTile);
+            drain(I1, A, kA, vs_prev);
+            K1_STAMP(8);
+        }
+        // ---- steps this wave has no keys for (the workgroup's other waves do)
+        while (t < nsteps) {
+            stage_step();
+            K1_STAMP(9);
+            step_end();
+        }
+        // a drain after the last step still reads the V ring, and the pieces requested past the last
+        // tile must have landed before the rings are filled again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#ifdef K1_ABL_NOBRANCH
+        asm volatile("" ::"s"(abl_sticky));
+#endif
+        mfma_fence();
+        K1_STAMP(10);  // last wait + barrier
+        const Epi e = {A, B, kv_off, pos_base, b, kvh, hg, hq, J, hu, tile_long, tile_short, liveA, liveB};
+        // CHAIN: the rings are free from here on (nobody reads them after the barrier above), so the
+        // next item is taken up between the two halves of the epilogue: its scalars are requested,
+        // block A's O goes out, its Q rows and first tiles are requested, block B's O goes out -- each
+        // request's latency behind a store's worth of work
+        bool more = false;
+        const KArgs ka = args();
+        if constexpr (CHAIN) {
+            item += ka.chain_gx;
+            ++nth;
+            if (item < ka.chain_items) prefetch_scalars(item, ka);
+        }
+        store(e, e.A, kA, e.liveA, ka);
+        if constexpr (CHAIN) {
+            while (item < ka.chain_items && !(more = setup(item, !PAGED && (nth & 1), ka))) {
+                item += ka.chain_gx;
+                ++nth;
+            }
+            if (more) request_first_tiles();
+        }
+#ifndef K1_RT
+        K1_STAMP(4);  // block A stored; next item taken up: geometry, Q loads and first tiles requested
+#endif
+        store(e, e.B, kB, e.liveB, ka);
+        K1_STAMP(3);  // epilogue
+        if (!more) break;
+    }
 #ifdef NVLLM_K1_STAMPS
-    K1_STAMP(3);  // epilogue
 #ifdef K1_RT
     seg_sum[4] = rt0_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_sum[9])::"memory");
@@ -1356,6 +1601,30 @@ __global__ __launch_bounds__(256) void flash_attn_ksplit_merge_kernel(
 
 }  // namespace
 
+namespace {
+// Chains per (unit, pair index) of a CHAIN launch, 0 = do not chain.  A workgroup that works through
+// several batch elements pays the hand-over between workgroups once, and every item after its first
+// has its Q rows and first K/V tiles on the way while the item before writes its O.  Workgroups are
+// still dealt out by the hardware as CUs fall free, so at least two rounds of them stay for the tail
+// to even out: chains of up to 4 items once there are four rounds of items.  NVLLM_K1_CHAIN = items
+// per chain (0 / 1 = no chaining).
+// Measured (profiles/r03_k1_chain.txt): dense B = 8 x 4096 533.7 -> 524.9 us with chains of 4; over
+// the cache (256 x 2048, T = 32 / 64) nothing either way -- an item's set-up costs ~6000 cycles
+// wherever it runs (one wave per SIMD, straight-line code that is cold in the instruction cache),
+// so moving it next to the epilogue hides little.  Default: the dense kernel chains, the paged one
+// does not unless NVLLM_K1_CHAIN asks.
+int chain_count(int64_t units, int batch, bool by_default) {
+    const int64_t cus = device_cus();
+    int64_t len = by_default ? units * batch / (2 * cus) : 0;
+    if (len > 4) len = 4;
+    if (const int forced = launch_policy().k1_chain; forced >= 0) len = forced;
+    if (len > batch) len = batch;
+    if (len < 2) return 0;
+    const int64_t nch = (batch + len - 1) / len;
+    return units * nch > 0x7fffffffLL ? 0 : (int)nch;
+}
+}  // namespace
+
 bool flash_attn_mfma_supported(const FlashAttnArgs &a) {
     if (a.head_dim != kD) return false;
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
@@ -1378,15 +1647,25 @@ hipError_t launch_flash_attn_mfma(const FlashAttnArgs &a, hipStream_t stream) {
     auto k = static_cast<const __bf16 *>(a.k);
     auto v = static_cast<const __bf16 *>(a.v);
     auto o = static_cast<__bf16 *>(a.o);
+    if (const int nch = chain_count((int64_t)grid.x, a.batch, true); a.causal && nch > 0) {
+        flash_attn_mfma_kernel<true, false, false, true><<<dim3(grid.x * (unsigned)nch), block, 0, stream>>>(
+            q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0, a.batch, nch);
+        return hipGetLastError();
+    }
+#ifdef K1_DEV_ONLY_CHAIN
+    return hipErrorUnknown;
+#else
     if (a.causal)
-        flash_attn_mfma_kernel<true, false, false><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<true, false, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0, 0, 0);
     else
-        flash_attn_mfma_kernel<false, false, false><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<false, false, false, false><<<grid, block, 0, stream>>>(
             q, k, v, o, a.lse, a.seq_q, a.seq_kv, a.num_heads, a.num_kv_heads, num_q_tiles,
-            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0);
+            pair_adjacent, scale_log2e, nullptr, nullptr, 0, 0u, nullptr, 0, 0, 0, 0);
     return hipGetLastError();
+#endif
 }
 
 // Chunked prefill / speculative verify over the paged cache: T new tokens per sequence against
@@ -1464,16 +1743,17 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     auto o = static_cast<__bf16 *>(a.out);
     const int parts = paged_ksplit_parts(a, g);
     const size_t need = (size_t)a.num_seqs * g.units * g.pairs * parts * kSplitSlotBytes;
+#ifndef K1_DEV_ONLY_CHAIN
     if (parts > 1) {
         // checked against flash_attn_paged_workspace_bytes by the C ABI (same policy, same arithmetic)
         if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15u) != 0)
             return hipErrorInvalidValue;
         auto ws = static_cast<unsigned char *>(a.workspace);
         const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs), 1u, (unsigned)parts);
-        flash_attn_mfma_kernel<true, true, true><<<grid, block, 0, stream>>>(
+        flash_attn_mfma_kernel<true, true, true, false><<<grid, block, 0, stream>>>(
             q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
             pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, ws,
-            g.gsh, a.num_seqs);
+            g.gsh, a.num_seqs, 0, 0);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         const dim3 mgrid(2 * kQTile / 4, (unsigned)(g.pairs * g.units), (unsigned)a.num_seqs);
@@ -1482,16 +1762,28 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
             pair_adjacent, parts, g.gsh);
         return hipGetLastError();
     }
+#endif
     const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs));
     float *lse_arg = nullptr;
 #ifdef NVLLM_K1_STAMPS  // diagnostic build only: the stamp buffer rides in the (unused) workspace
     lse_arg = static_cast<float *>(a.workspace);
 #endif
-    flash_attn_mfma_kernel<true, true, false><<<grid, block, 0, stream>>>(
+    if (const int nch = chain_count((int64_t)g.pairs * g.units, a.num_seqs, false); nch > 0) {
+        flash_attn_mfma_kernel<true, true, false, true><<<dim3((unsigned)(g.pairs * g.units * nch)), block, 0, stream>>>(
+            q, kc, vc, o, lse_arg, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
+            pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, nullptr,
+            g.gsh, a.num_seqs, a.num_seqs, nch);
+        return hipGetLastError();
+    }
+#ifdef K1_DEV_ONLY_CHAIN
+    return hipErrorUnknown;
+#else
+    flash_attn_mfma_kernel<true, true, false, false><<<grid, block, 0, stream>>>(
         q, kc, vc, o, lse_arg, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
         pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, nullptr,
-        g.gsh, a.num_seqs);
+        g.gsh, a.num_seqs, 0, 0);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace kernels

@@ -14,8 +14,17 @@
 // g / row_vec, found with one division; the slot is a cached vector load shared by the row's
 // lanes).  Against one wave per token this halves a 4096-token launch (19 -> 9 us) because every
 // CU sees many short independent threads instead of a few waves that each wait on their slot.
-// Prefill-sized launches stream: non-temporal loads and stores (4.4 -> 5.1 TB/s at 32k tokens);
-// a decode step's few rows use ordinary stores so the attention kernel finds them in cache.
+// Launches whose K/V rows exceed what the Infinity Cache can still hold from their producer (>= 48 MiB)
+// stream: non-temporal loads and stores (4.4 -> 5.1 TB/s at 32k tokens); smaller ones use ordinary
+// accesses (a 4096-token launch: 8.0 -> 6.7 us), and a decode step's few rows stay in cache for the
+// attention kernel.
+//
+// Where the remaining gap to the copy ceiling lies (scripts/k4_lab, profiles/r03_k4_lab.txt): with
+// slots in order this kernel runs at the speed of a straight copy of the same bytes (6.0 TB/s, 0.75
+// of 8 TB/s) and FETCH_SIZE / WRITE_SIZE equal the algorithmic bytes; whole blocks in ascending order
+// give 5.8, whole blocks or single rows in random order 5.2-5.3 -- the same for every mapping tried
+// (flat, one wave per 1 / 2 / 4 rows with scalar slots and all loads first, resident waves with the
+// next row in flight), so the loss is the DRAM's for scattered 2-32 KiB writes, not the kernel's.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -132,8 +141,8 @@ hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     const u32x4 *k = static_cast<const u32x4 *>(key), *v = static_cast<const u32x4 *>(value);
     u32x4 *kc = static_cast<u32x4 *>(k_cache), *vc = static_cast<u32x4 *>(v_cache);
-    constexpr int64_t kStreamTokens = 2048;
-    if (num_tokens >= kStreamTokens)
+    constexpr int64_t kStreamBytes = 48ll << 20;  // K + V rows of the launch
+    if (2 * num_tokens * row_bytes >= kStreamBytes)
         reshape_and_cache_kernel<true><<<grid, block, 0, stream>>>(k, v, kc, vc, slot_mapping, total,
                                                                    row_vec, num_slots);
     else

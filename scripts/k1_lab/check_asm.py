@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Audit a K1 .s: no compiler-generated AGPR traffic outside inline-asm statements, no spills,
-no VALU write of an MFMA operand right in front of an MFMA, M0 only inside the LDS-DMA statements,
+"""Audit a K1 .s: no compiler-generated AGPR traffic outside inline-asm statements, no scratch
+access (spill traffic) inside the step loops (loop depth >= 2; the chained kernel's item loop, depth
+1, may keep a few lane constants in scratch between items), no VALU write of an MFMA operand right in front of an MFMA, M0 only inside the LDS-DMA statements,
 no VALU-written SGPR (v_readlane / v_readfirstlane: an SGPR spill reload) read as the descriptor or
 scalar offset of an LDS-DMA load within the 5 wait states the hardware needs."""
 import re, sys
@@ -48,7 +49,9 @@ for n, l in enumerate(lines, 1):
 for k, (n, l) in enumerate(code):
     if re.search(r'buffer_load.* lds$', l):
         dmas += 1
-        if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or code[k - 1][1] != 's_nop 0':
+        # ... followed by one wait state: s_nop 0, or the scalar move that carries the tile offset
+        if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or not (
+                code[k - 1][1] == 's_nop 0' or re.match(r's_mov_b32 s\d+, s\d+$', code[k - 1][1])):
             m0bad.append((n, l))
 # VALU write of an SGPR -> VMEM read of it needs 5 wait states; hipcc pads its own instructions,
 # not the inside of an asm statement (which starts with s_mov m0 + s_nop 0 = 2 states)
@@ -70,6 +73,19 @@ for k, (n, l) in enumerate(code):
             if sregs(pl.split(None, 1)[1].split(',')[0].strip()) & used: shaz.append((n, pl, l))
         m = re.match(r's_nop (\d+)', pl)
         states += (int(m.group(1)) + 1) if m else 1
+# scratch traffic by loop depth (hipcc annotates every block label with its loop depth)
+deep, depth, per_depth = [], 0, {}
+for n, l in enumerate(lines, 1):
+    if re.match(r'\.LBB\d+_\d+:', l):
+        m = re.search(r'Depth=(\d+)', l)
+        depth = int(m.group(1)) if m else 0
+    elif re.match(r'\S+:\s*(;.*)?$', l) and not l.startswith('.L'):
+        depth = 0  # a new function
+    if re.match(r'\s*scratch_(load|store)', l):
+        per_depth[depth] = per_depth.get(depth, 0) + 1
+        if depth >= 2: deep.append((n, l.strip()))
+print("scratch accesses by loop depth:", dict(sorted(per_depth.items())), " inside step loops:", len(deep))
+for h in deep[:6]: print(h)
 print("VALU-written SGPR -> LDS-DMA descriptor within 5 wait states:", len(shaz))
 for h in shaz[:6]: print(h)
 print("LDS-DMA loads:", dmas, " M0 uses outside / malformed DMA statements:", len(m0bad))
@@ -81,4 +97,4 @@ for n, l in bad[:10]: print(n, l)
 for key in ('.vgpr_spill_count', '.sgpr_spill_count', '.private_segment_fixed_size', '.vgpr_count', '.agpr_count', '.sgpr_count'):
     for line in open(sys.argv[1]):
         if key in line: print(line.strip())
-sys.exit(1 if (bad or haz or m0bad or shaz) else 0)
+sys.exit(1 if (bad or haz or m0bad or shaz or deep) else 0)

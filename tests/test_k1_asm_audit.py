@@ -4,8 +4,10 @@ K1 keeps its accumulators and Q fragments in literally named AGPRs and issues it
 inline asm, which hipcc neither schedules around nor pads hazards for.  The audit
 (scripts/k1_lab/check_asm.py) compiles nothing itself; this test cross-compiles the kernel to
 gfx950 assembly and requires: no compiler-generated use of the owned AGPR range outside the asm
-statements, no register spills, and no VALU write of an MFMA operand within the two
-instructions in front of an MFMA statement."""
+statements, no scratch (spill) traffic inside the step loops, no VALU write of an MFMA operand
+within the two instructions in front of an MFMA statement, no VALU-written SGPR read by an LDS-DMA
+load within 5 wait states.  Vector-register spills: none in any variant but the chained paged one
+(opt-in, NVLLM_K1_CHAIN), which keeps a few lane constants in scratch BETWEEN items."""
 import os
 import subprocess
 import sys
@@ -28,5 +30,8 @@ def test_k1_isa_audit(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     text = r.stdout
-    assert ".vgpr_spill_count: 0" in text
-    assert ".private_segment_fixed_size: 0" in text
+    assert "inside step loops: 0" in text
+    spills = [int(l.split(":")[1]) for l in text.splitlines() if l.startswith(".vgpr_spill_count")]
+    assert len(spills) == 7, text                   # merge kernel + six instantiations of the K1 kernel
+    assert sorted(spills)[:-1] == [0] * 6, spills   # at most one variant spills at all ...
+    assert max(spills) <= 24, spills                # ... and that one only a handful of registers
