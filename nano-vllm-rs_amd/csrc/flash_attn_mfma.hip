@@ -50,7 +50,7 @@
 // design) must never reach the product library: they compile only when the lab says who it is.
 #if !defined(NVLLM_K1_LAB) &&                                                                      \
     (defined(NVLLM_K1_STAMPS) || defined(K1_FINE) || defined(K1_RT) || defined(K1_ABL_NOVALU) ||   \
-     defined(K1_DEV_ONLY_CHAIN) ||                                                                 \
+     defined(K1_DEV_ONLY_CHAIN) || defined(K1_STAMP_SETUP) ||                                                                 \
      defined(K1_ABL_NOSTAGE) || defined(K1_ABL_NOBRANCH) || defined(K1_ABL_SKIP_KINDS) ||          \
      defined(K1_DBG_VALU_L) || defined(K1_DBG_FENCE))
 #error "K1 lab switch (NVLLM_K1_STAMPS / K1_ABL_* / K1_DBG_*) defined without NVLLM_K1_LAB: not a product build"
@@ -575,12 +575,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // a light one).  false = the item has no rows (PAGED: the grid is sized for pos_shift = 31).
     auto setup = [&](int cb, bool flip, const KArgs &ka) -> bool {
         const int tid_f = CHAIN ? fresh(tid) : tid;
-        const int c = tid_f & 31, h = (tid_f >> 5) & 1;  // (shadow the kernel's: not hoistable)
+        const int c = tid_f & 31;  // (shadows the kernel's: not hoistable)
         const int Sq = ka.Sq, Hq = ka.Hq, Hkv = ka.Hkv, num_seqs = ka.num_seqs;
         const int max_blocks_per_seq = ka.max_blocks_per_seq, pair_adjacent = ka.pair_adjacent;
         const int gsh = PAGED ? ka.pack_shift : 0, gp = 1 << gsh, G = Hq / Hkv;
         const int32_t *block_tables = ka.block_tables, *context_lens = ka.context_lens;
-        const __bf16 *q = ka.q, *k = ka.k, *v = ka.v;
+        const __bf16 *k = ka.k, *v = ka.v;
         const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
         if constexpr (CHAIN) {
             kvh = ch_kvh;
@@ -690,21 +690,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         B.qrow = ((rowB0 + c) >> gsh) + pos_base;
         A.r0 = rowA0;
         B.r0 = rowB0;
-        auto issue_q = [&](Block &blk, bool live, u32x4 (&x)[8]) {
-            const int row = blk.qrow - kv_off;
-            const bool ok = live && row >= 0 && row < Sq;
-            const __bf16 *qp = q + (((int64_t)b * Sq + (ok ? row : 0)) * Hq + hq) * kD + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                x[ks] = u32x4{0u, 0u, 0u, 0u};
-                if (ok) x[ks] = *reinterpret_cast<const u32x4 *>(qp + 16 * ks);
-            }
-            blk.m = -INFINITY;
-            blk.mc = 0.0f;
-            blk.thr = -INFINITY;
-        };
-        issue_q(A, liveA, qa);
-        issue_q(B, liveB, qb);
+        A.m = B.m = -INFINITY;
+        A.mc = B.mc = 0.0f;
+        A.thr = B.thr = -INFINITY;
         // (uni: these feed "s" operands of the DMA statements; CHAIN's arguments come out of LDS and
         // hipcc would otherwise carry what is computed from them in vector registers)
         auto uni = [](unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); };
@@ -724,6 +712,30 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             dma_vrs = u32x4{uni((unsigned)va), uni((unsigned)(va >> 32) & 0xffffu), uni(kv_bytes), 0x00020000u};
         }
         return true;
+    };
+    // The item's Q rows, into qa / qb.  Issued AFTER the first tiles' requests: hipcc shuffles the
+    // staging registers of a chained item (they are loop-carried) and waits for the loads where it
+    // does, and the DMA requests must not stand behind that wait.
+    auto load_q = [&](const KArgs &ka) {
+        const int tid_f = CHAIN ? fresh(tid) : tid;
+        const int h = (tid_f >> 5) & 1;
+        // buffer loads over this batch element's Q rows: a row the block does not have gets an
+        // offset past the buffer and reads as zero -- no branch around the loads (hipcc waits for
+        // every outstanding load where such a branch joins)
+        const unsigned seq_bytes = (unsigned)ka.Sq * (unsigned)ka.Hq * (unsigned)(kD * 2);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(ka.q + (int64_t)b * ka.Sq * ka.Hq * kD), 0, (int)seq_bytes, 0x00020000);
+        auto issue_q = [&](const Block &blk, bool live, u32x4 (&x)[8]) {
+            const int row = blk.qrow - kv_off;
+            const bool ok = live && row >= 0 && row < ka.Sq;
+            const unsigned off = ok ? ((unsigned)row * (unsigned)ka.Hq + (unsigned)hq) * (unsigned)(kD * 2) + 16u * h
+                                    : 0xffffff00u;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                x[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 32u * ks), 0, 0));
+        };
+        issue_q(A, liveA, qa);
+        issue_q(B, liveB, qb);
     };
     auto prefetch_scalars = [&](int cb, const KArgs &ka) {
         if constexpr (CHAIN && PAGED) {
@@ -1416,8 +1428,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             have = setup(0, false, ka);
         }
         if (!have) return;
+        request_first_tiles();
+        load_q(ka);
     }
-    request_first_tiles();
     for (;;) {
         finish_prologue();
         clear_item(I0);
@@ -1487,14 +1500,26 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             if (item < ka.chain_items) prefetch_scalars(item, ka);
         }
         store(e, e.A, kA, e.liveA, ka);
+#ifdef K1_STAMP_SETUP  // lab: store A -> 4, set-up -> 14, requests -> 1 (only meaningful where no dual step runs)
+        K1_STAMP(4);
+#endif
         if constexpr (CHAIN) {
             while (item < ka.chain_items && !(more = setup(item, !PAGED && (nth & 1), ka))) {
                 item += ka.chain_gx;
                 ++nth;
             }
-            if (more) request_first_tiles();
+#ifdef K1_STAMP_SETUP
+            K1_STAMP(14);
+#endif
+            if (more) {
+                request_first_tiles();
+                load_q(ka);
+            }
+#ifdef K1_STAMP_SETUP
+            K1_STAMP(1);
+#endif
         }
-#ifndef K1_RT
+#if !defined(K1_RT) && !defined(K1_STAMP_SETUP)
         K1_STAMP(4);  // block A stored; next item taken up: geometry, Q loads and first tiles requested
 #endif
         store(e, e.B, kB, e.liveB, ka);
@@ -1608,11 +1633,11 @@ namespace {
 // still dealt out by the hardware as CUs fall free, so at least two rounds of them stay for the tail
 // to even out: chains of up to 4 items once there are four rounds of items.  NVLLM_K1_CHAIN = items
 // per chain (0 / 1 = no chaining).
-// Measured (profiles/r03_k1_chain.txt): dense B = 8 x 4096 533.7 -> 524.9 us with chains of 4; over
-// the cache (256 x 2048, T = 32 / 64) nothing either way -- an item's set-up costs ~6000 cycles
-// wherever it runs (one wave per SIMD, straight-line code that is cold in the instruction cache),
-// so moving it next to the epilogue hides little.  Default: the dense kernel chains, the paged one
-// does not unless NVLLM_K1_CHAIN asks.
+// Measured (profiles/r03_k1_chain.txt): dense B = 8 x 4096 520.9 -> 511.0 us with chains of 4; over
+// the cache (256 x 2048, T = 32 / 64) nothing: taking up an item costs 3700-7000 cycles wherever it
+// stands (one wave per SIMD, nothing else to issue), so the chain saves the hand-over between
+// workgroups and little else, and the paged kernel's spill reloads wait for the next item's Q
+// loads.  Default: the dense kernel chains, the paged one does not unless NVLLM_K1_CHAIN asks.
 int chain_count(int64_t units, int batch, bool by_default) {
     const int64_t cus = device_cus();
     int64_t len = by_default ? units * batch / (2 * cus) : 0;
@@ -1629,8 +1654,9 @@ bool flash_attn_mfma_supported(const FlashAttnArgs &a) {
     if (a.head_dim != kD) return false;
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
     if (a.batch > 65535 || a.seq_q <= 0 || a.seq_kv <= 0) return false;
-    // K/V of one batch element are addressed with 32-bit buffer offsets
+    // K/V (and Q) of one batch element are addressed with 32-bit buffer offsets
     if ((int64_t)(a.seq_kv + 3 * kKV) * a.num_kv_heads * kD * 2 >= (int64_t)1 << 31) return false;
+    if ((int64_t)a.seq_q * a.num_heads * kD * 2 >= (int64_t)1 << 31) return false;
     const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     return al(a.q) && al(a.k) && al(a.v) && al(a.o);
 }
@@ -1676,6 +1702,7 @@ bool flash_attn_paged_supported(DType dt, const PagedAttnArgs &a) {
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0) return false;
     if (a.num_seqs <= 0 || a.num_seqs > 65535 || a.num_new_tokens <= 0) return false;
     if (a.max_blocks_per_seq <= 0 || a.max_blocks_per_seq > (1 << 26)) return false;
+    if ((int64_t)a.num_new_tokens * a.num_heads * kD * 2 >= (int64_t)1 << 31) return false;  // Q rows of a sequence
     // a block is addressed through its own buffer descriptor (64-bit base, 32-bit offset inside the
     // block), so the cache may have any size; ids are unsigned 32-bit values below num_cache_blocks
     if (a.num_cache_blocks <= 0 || a.num_cache_blocks > (int64_t)0x7fffffff || a.num_kv_heads >= (1 << 15))

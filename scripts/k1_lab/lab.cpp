@@ -132,7 +132,7 @@ static int paged_main(int N, int ctx, int Hq, int Hkv, int T, int rounds, int it
                    v.name, (double)(t1 - t0) * 0.01, dur / n * 0.01, late[0], late[1], late[2], late[3], late[4], late[5]);
             sum[4] = sum[9] = 0;
         }
-        printf("%-14s stamps over %zu waves: steps/wave %.1f, c12=%.1f c13=%.1f\n", v.name, n, sum[15] / n, sum[12] / n, sum[13] / n);
+        printf("%-14s stamps over %zu waves: steps/wave %.1f, c12=%.1f c13=%.1f s14=%.0f\n", v.name, n, sum[15] / n, sum[12] / n, sum[13] / n, sum[14] / n);
         printf("%-14s   cycles per wave: ", v.name);
         double tot = 0;
         for (int i = 0; i < 12; ++i) { printf("s%d=%.0f ", i, sum[i] / n); tot += sum[i]; }
