@@ -265,6 +265,20 @@ int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64
 int nvllm_debug_set_policy(const char *name, int value);
 void nvllm_debug_reset_policy(void);
 
+/* Debug check of a launch's tables, no counterpart in the reference (whose
+ * index_select fails on a bad id, src/attention/paged.rs:134-146): the kernels
+ * here never fault on a wrong table -- an id outside the pool reads as zeros or
+ * is clamped, a context length is clamped into its table row -- so a wrong
+ * table gives plausible wrong output.  This pass counts what a launch over the
+ * same tables would have clamped, into `counts` (DEVICE memory, 2 ints, zeroed
+ * by the call): counts[0] = ids < 0 or >= num_cache_blocks among the
+ * ceil(context_len / block_size) blocks each sequence uses, counts[1] =
+ * context lengths < 0 or > max_blocks_per_seq * block_size.  Asynchronous on
+ * `stream`; not meant for the serving loop. */
+int nvllm_debug_validate_tables(const int32_t *block_tables, const int32_t *context_lens, int num_seqs,
+                                int max_blocks_per_seq, int block_size, int64_t num_cache_blocks,
+                                int32_t *counts, nvllm_stream_t stream);
+
 /* Device inventory used by the sharded launcher and the bench.  nvllm_set_device also resolves
  * the no-allocation entry's scratch address on that device. */
 int nvllm_device_count(void);

@@ -19,6 +19,6 @@ from .core import (  # noqa: F401
 )
 from .attention import (  # noqa: F401
     FlashAttentionConfig, flash_attention, prefill_attention, paged_attention,
-    paged_attention_batched, paged_attention_path, write_kv_to_cache, reshape_and_cache, RotaryEmbedding,
+    paged_attention_batched, paged_attention_path, validate_tables, write_kv_to_cache, reshape_and_cache, RotaryEmbedding,
     qk_norm_rope_cache,
 )

@@ -131,6 +131,20 @@ def paged_attention_path(num_seqs, num_new_tokens, num_heads, num_kv_heads, head
     return PAGED_PATHS[code]
 
 
+def validate_tables(block_tables, context_lens, block_size, num_cache_blocks):
+    """nvllm_debug_validate_tables: (ids outside the pool among the blocks the context lengths use,
+    context lengths outside their table row) -- what a launch over these tables would silently clamp."""
+    _require_device(block_tables, context_lens)
+    assert block_tables.dtype == torch.int32 and context_lens.dtype == torch.int32
+    assert block_tables.is_contiguous() and context_lens.is_contiguous()
+    counts = torch.empty(2, dtype=torch.int32, device=block_tables.device)
+    check(capi.lib().nvllm_debug_validate_tables(block_tables.data_ptr(), context_lens.data_ptr(),
+                                                 block_tables.shape[0], block_tables.shape[1], block_size,
+                                                 num_cache_blocks, counts.data_ptr(), _stream()))
+    bad_ids, bad_lens = counts.tolist()
+    return bad_ids, bad_lens
+
+
 def paged_attention_batched(query, key_cache, value_cache, block_tables, context_lens, scale,
                             workspace=None):
     """Batched form (nvllm_paged_attn_*): query [num_seqs,T,Hq,D], block_tables int32

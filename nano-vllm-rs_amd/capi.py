@@ -45,6 +45,7 @@ SIGNATURES = {
     "nvllm_kv_cache_layer_bytes": (_i64, [_i64, _i64, _i64, _i64, _i]),
     "nvllm_kv_cache_total_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _i]),
     "nvllm_debug_set_policy": (_i, [_c.c_char_p, _i]),
+    "nvllm_debug_validate_tables": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp]),
     "nvllm_debug_reset_policy": (None, []),
     "nvllm_device_count": (_i, []),
     "nvllm_set_device": (_i, [_i]),

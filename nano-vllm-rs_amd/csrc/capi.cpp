@@ -282,6 +282,17 @@ int nvllm_debug_set_policy(const char *name, int value) {
 
 void nvllm_debug_reset_policy(void) { kernels::reset_launch_policy(); }
 
+int nvllm_debug_validate_tables(const int32_t *block_tables, const int32_t *context_lens, int num_seqs,
+                                int max_blocks_per_seq, int block_size, int64_t num_cache_blocks,
+                                int32_t *counts, nvllm_stream_t stream) {
+    if (!block_tables || !context_lens || !counts) return fail(ErrorKind::Null, "debug_validate_tables: null pointer");
+    if (num_seqs <= 0 || max_blocks_per_seq <= 0 || block_size <= 0 || num_cache_blocks <= 0)
+        return fail(ErrorKind::Config, "debug_validate_tables: negative or zero dimension");
+    return hip_status(kernels::launch_validate_tables(block_tables, context_lens, num_seqs, max_blocks_per_seq,
+                                                      block_size, num_cache_blocks, counts, as_stream(stream)),
+                      "debug_validate_tables launch");
+}
+
 int64_t nvllm_kv_cache_layer_bytes(int64_t num_blocks, int64_t block_size, int64_t num_kv_heads,
                                    int64_t head_dim, int dtype) {
     if (num_blocks < 0 || block_size < 0 || num_kv_heads < 0 || head_dim < 0 || (dtype != 0 && dtype != 1))

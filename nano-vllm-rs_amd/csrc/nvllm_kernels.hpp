@@ -48,6 +48,12 @@ hipError_t launch_reshape_and_cache(const void *key, const void *value, void *k_
 hipError_t launch_gather_blocks(const void *cache, const int32_t *ids, void *out, int64_t num_ids,
                                 int64_t block_bytes, int64_t num_cache_blocks, hipStream_t stream);
 
+// nvllm_debug_validate_tables (paged_attn.hip): counts[0] = ids outside the pool among the used
+// blocks, counts[1] = context lengths outside their table row; counts is device memory (2 ints)
+hipError_t launch_validate_tables(const int32_t *block_tables, const int32_t *context_lens, int num_seqs,
+                                  int max_blocks_per_seq, int block_size, int64_t num_cache_blocks,
+                                  int32_t *counts, hipStream_t stream);
+
 // K5: qk_norm_rope_cache.hip
 struct QkNormRopeCacheArgs {
     const void *q;

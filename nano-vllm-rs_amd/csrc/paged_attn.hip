@@ -851,5 +851,41 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
     return hipGetLastError();
 }
 
+// nvllm_debug_validate_tables: the attention kernels clamp an id outside the pool (or read it as
+// zeros) and a context length outside its table row, so a wrong table gives plausible wrong output
+// instead of a fault.  This pass counts what they would have had to clamp: counts[0] = ids < 0 or
+// >= num_cache_blocks among the blocks a sequence's context length says it uses, counts[1] =
+// context lengths < 0 or beyond max_blocks_per_seq * block_size.  One wave per sequence.
+namespace {
+__global__ __launch_bounds__(64) void validate_tables_kernel(const int32_t *__restrict__ block_tables,
+                                                             const int32_t *__restrict__ context_lens,
+                                                             int max_blocks_per_seq, int block_size,
+                                                             int64_t num_cache_blocks, int32_t *__restrict__ counts) {
+    const int seq = blockIdx.x;
+    const int ctx = context_lens[seq];
+    const int64_t cap = (int64_t)max_blocks_per_seq * block_size;
+    const bool bad_len = ctx < 0 || ctx > cap;
+    if (bad_len && threadIdx.x == 0) atomicAdd(counts + 1, 1);
+    const int used = bad_len ? (ctx < 0 ? 0 : max_blocks_per_seq) : (ctx + block_size - 1) / block_size;
+    int bad = 0;
+    for (int i = threadIdx.x; i < used; i += 64) {
+        const int64_t id = block_tables[(int64_t)seq * max_blocks_per_seq + i];
+        bad += id < 0 || id >= num_cache_blocks;
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+    if (bad && threadIdx.x == 0) atomicAdd(counts, bad);
+}
+}  // namespace
+
+hipError_t launch_validate_tables(const int32_t *block_tables, const int32_t *context_lens, int num_seqs,
+                                  int max_blocks_per_seq, int block_size, int64_t num_cache_blocks,
+                                  int32_t *counts, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), stream);
+    if (err != hipSuccess) return err;
+    validate_tables_kernel<<<dim3((unsigned)num_seqs), dim3(64), 0, stream>>>(
+        block_tables, context_lens, max_blocks_per_seq, block_size, num_cache_blocks, counts);
+    return hipGetLastError();
+}
+
 }  // namespace kernels
 }  // namespace nvllm

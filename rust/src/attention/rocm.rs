@@ -259,6 +259,41 @@ pub fn workspace_bytes(n: usize, t: usize, hq: usize, hkv: usize, d: usize, bs: 
     }
 }
 
+/// Which kernel a batched launch of this shape runs (pure query, nvllm_paged_attn_path).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum PagedPath {
+    Decode,
+    K1Paged,
+    Generic,
+}
+
+#[allow(clippy::too_many_arguments)]
+pub fn paged_attention_path(n: usize, t: usize, hq: usize, hkv: usize, d: usize, bs: usize, max_blocks: usize,
+                            num_cache_blocks: usize) -> Result<PagedPath> {
+    let code = unsafe {
+        ffi::nvllm_paged_attn_path(n as c_int, t as c_int, hq as c_int, hkv as c_int, d as c_int, bs as c_int,
+                                   max_blocks as c_int, num_cache_blocks as i64, 0)
+    };
+    match code {
+        0 => Ok(PagedPath::Decode),
+        1 => Ok(PagedPath::K1Paged),
+        2 => Ok(PagedPath::Generic),
+        e => check(e).map(|_| PagedPath::Generic),
+    }
+}
+
+/// Debug pass over a launch's tables (nvllm_debug_validate_tables): fills `counts` (device, 2 x i32)
+/// with the ids outside the pool among the used blocks and the context lengths outside their rows.
+#[allow(clippy::too_many_arguments)]
+pub fn validate_tables(block_tables: *const i32, context_lens: *const i32, num_seqs: usize,
+                       max_blocks_per_seq: usize, block_size: usize, num_cache_blocks: usize,
+                       counts: *mut i32, stream: ffi::Stream) -> Result<()> {
+    check(unsafe {
+        ffi::nvllm_debug_validate_tables(block_tables, context_lens, num_seqs as c_int, max_blocks_per_seq as c_int,
+                                         block_size as c_int, num_cache_blocks as i64, counts, stream)
+    })
+}
+
 /// Batched KV write: key/value [num_tokens,Hkv,D], device `slot_mapping` i64 [num_tokens].
 pub fn reshape_and_cache(
     key: &DeviceTensor,

@@ -313,3 +313,20 @@ def test_paged_equals_contiguous_sdpa_round_trip(dev):
     s = torch.einsum("hd,shd->hs", q[0, 0].float(), kf) / math.sqrt(D)
     ref = torch.einsum("hs,shd->hd", torch.softmax(s, dim=-1), vf).reshape(1, 1, Hq * D)
     assert_attention_close(out.cpu().numpy(), ref.cpu().numpy())
+
+
+def test_debug_validate_tables_counts_what_a_launch_would_clamp(dev):
+    # nvllm_debug_validate_tables (no reference counterpart: paged.rs:134-146 index_select fails on
+    # a bad id; the kernels here clamp or read zeros).  Only the blocks a context length uses count.
+    bs, nb, max_blocks = 16, 100, 8
+    bt = torch.tensor([[1, 2, 3, 99, -1, 500, 0, 0],          # ctx 40 -> 3 blocks used: clean
+                       [5, 100, -7, 6, 7, 8, 9, 10],          # ctx 128 -> 8 used: 100 and -7 are bad
+                       [0, 1, 2, 3, 4, 5, 6, 7],              # ctx too long for the row
+                       [-1, -1, -1, -1, -1, -1, -1, -1]],     # ctx 0: nothing used
+                      dtype=torch.int32, device=dev)
+    cl = torch.tensor([40, 128, 129, 0], dtype=torch.int32, device=dev)
+    assert nv.validate_tables(bt, cl, bs, nb) == (2, 1)
+    cl_ok = torch.tensor([40, 16, 128, 0], dtype=torch.int32, device=dev)
+    assert nv.validate_tables(bt, cl_ok, bs, nb) == (0, 0)
+    cl_neg = torch.tensor([-3, 16, 128, 0], dtype=torch.int32, device=dev)
+    assert nv.validate_tables(bt, cl_neg, bs, nb) == (0, 1)
