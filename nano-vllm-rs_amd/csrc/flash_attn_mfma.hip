@@ -79,12 +79,19 @@ constexpr int kKRow = 256, kKTile = kKV * kKRow;  // 16 KiB, likewise (conflict-
 // instruction writes 1 KiB linearly, so both images have plain 256-byte rows and the swizzle is
 // applied through each lane's SOURCE address.  K ring of 3: a tile is requested two steps before
 // it is read; V ring of 3: one step before, and read a step later than K.
-constexpr int kVRing = 3, kKRing = 3;
-constexpr int kKBase = kVRing * kVTile;
-constexpr int kLdsBytes = kKBase + kKRing * kKTile;  // 98,304 B
+// Ring depth: 3 + 3 (98,304 B; K requested two tiles ahead, V one).  The kernel also builds with
+// rings of 4 + 4 (K three tiles, V two tiles ahead, 131,072 B), tried in round 3 for the paged
+// kernel's short-chunk shapes, which stream K/V from HBM at one workgroup per CU: SLOWER everywhere
+// (256 x 2048: T = 16 412.7 -> 428.8 us, T = 32 442.8 -> 448.9, T = 64 636.5 -> 647.2; 16 x 4096
+// T = 64 101.6 -> 119.5) -- the prologue has two more tiles to wait for and the steps gain nothing,
+// so those shapes are not bound by the bytes a CU keeps in flight.
+constexpr int ring_depth(bool paged, bool chain) { return (void)paged, (void)chain, 3; }
+constexpr int ring_bytes(int depth) { return depth * (kVTile + kKTile); }
 constexpr int kORow = 272, kOStage = 32 * kORow;  // epilogue: O rows of a block, padded
 constexpr int kArgsCopy = 128;                    // CHAIN: a wave's copy of the kernel arguments (KArgs)
-static_assert(kLdsBytes + kWaves * (kOStage + kArgsCopy) <= 160 * 1024, "rings + O staging must fit the CU's LDS");
+static_assert(ring_bytes(3) + kWaves * (kOStage + kArgsCopy) <= 160 * 1024 && ring_bytes(4) <= 160 * 1024 &&
+                  kWaves * kOStage <= ring_bytes(3),
+              "rings + O staging must fit the CU's LDS");
 constexpr float kDeferLog2 = 6.0f;  // rescale only when a row max grows by > 2^6 (T13)
 
 // Diagnostic build only (scripts/k1_lab, -DNVLLM_K1_STAMPS): per-wave cycle sums of the loop's
@@ -422,7 +429,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     static_assert(!CHAIN || !KSPLIT, "a key-split launch has fewer workgroups than CUs: nothing to chain");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes + kWaves * kOStage + kWaves * kArgsCopy];
+    constexpr int kRing = ring_depth(PAGED, CHAIN);          // K and V ring slots
+    constexpr int kKAhead = kRing - 1, kVAhead = kRing - 2;  // step t requests K(t + kKAhead), V(t + kVAhead)
+    constexpr int kKBase = kRing * kVTile;
+    constexpr int kLdsBytes = ring_bytes(kRing);
+    // O staging: behind the rings when the next item's tiles may already be landing in them (CHAIN),
+    // else in the rings themselves, free after an item's last barrier
+    constexpr int kOStageBase = CHAIN ? kLdsBytes : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes + (CHAIN ? kWaves * (kOStage + kArgsCopy) : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // position of query row 0 minus row 0 (kv_off), split into a multiple of 32 (pos_base, where
     // the tiling starts) and the dead rows in front of the first block (pos_shift)
     int kv_off = 0, pos_base = 0, pos_shift = 0;
-    unsigned early_id[4] = {0u, 0u, 0u, 0u};
+    unsigned early_id[5] = {0u, 0u, 0u, 0u, 0u};
     int tile_long = 0, tile_short = 0, nA = 0, nB = 0, nsteps = 0;
     int tile0 = 0;  // KSPLIT: first key tile of this part
     bool liveA = false, liveB = false;
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     unsigned dma_kv[4] = {0u, 0u, 0u, 0u}, dma_vv = 0u;
     u32x4 dma_krs = {0u, 0u, 0u, 0u}, dma_vrs = {0u, 0u, 0u, 0u};  // dense: this item's K / V rows
     unsigned dma_pk[4] = {0u, 0u, 0u, 0u}, dma_pv[4] = {0u, 0u, 0u, 0u};
-    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0;  // id of the wave's block in tiles t+1, t+2, t+3
+    unsigned pg_s0 = 0, pg_s1 = 0, pg_s2 = 0, pg_s3 = 0;  // id of the wave's block in tiles t+1 .. t+4 (the last one only with rings of 4)
     unsigned long long pg_kbase = 0, pg_vbase = 0;  // PAGED: the caches from this item's kv head on
     unsigned pg_nrec = 0;                           // ... and what is left of a block from there
     constexpr unsigned kPgOutOfBlock = 0x40000000u;  // an offset no block reaches (Hkv < 2^15)
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                 for (int i = 0; i < 4; ++i) early_id[i] = pf_id[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < kRing + 1; ++i) {
                     int bi = 4 * i + wave;
                     bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
                     early_id[i] = (unsigned)block_tables[(int64_t)b * max_blocks_per_seq + bi];
@@ -1141,20 +1155,29 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             pg_s0 = early_id[1];
             pg_s1 = early_id[2];
             pg_s2 = early_id[3];
+            if constexpr (kRing == 4) pg_s3 = early_id[4];
         } else if constexpr (PAGED) {
             id0 = dma_id(0);
             pg_s0 = dma_id(1);
             pg_s1 = dma_id(2);
             pg_s2 = dma_id(3);
+            if constexpr (kRing == 4) pg_s3 = dma_id(4);
         }
+        // K tiles 0 .. kKAhead - 1 and V tiles 0 .. kVAhead - 1, tile i into slot i, oldest first
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma_piece(0, 0, 0, j, id0, true);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma_piece(1, 1, 0, j, pg_s0, true);
 #pragma unroll
         for (int j = 4; j < 8; ++j) dma_piece(0, 0, 0, j, id0, true);
+        if constexpr (kRing == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_piece(2, 2, 0, j, pg_s1, true);
+#pragma unroll
+            for (int j = 4; j < 8; ++j) dma_piece(1, 0, 1, j, pg_s0, true);
+        }
     };
-    // ... second half: accumulators zeroed, Q^T written, V slot 2 ("tile -1") zeroed, tiles landed
+    // ... second half: accumulators zeroed, Q^T written, the last V slot ("tile -1") zeroed, tiles landed
     auto finish_prologue = [&]() {
         zero_acc(kA);
         zero_acc(kB);
@@ -1170,7 +1193,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         const int tid_f = CHAIN ? fresh(tid) : tid;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<u32x4 *>(lds + 2 * kVTile + (i * 256 + tid_f) * 16) = z;
+            *reinterpret_cast<u32x4 *>(lds + (kRing - 1) * kVTile + (i * 256 + tid_f) * 16) = z;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -1191,9 +1214,16 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         it.xf = -INFINITY; it.ya = 0.0f; it.yb = 0.0f;
     };
 
-    int vs_prev = 2, vs_cur = 0, vs_next = 1;  // V ring slots of tiles t-1, t, t+1
-    int ks_cur = 0;                            // K ring slot of tile t
-    int ks_n1 = 1, ks_n2 = 2;                  // K ring slots of tiles t+1, t+2
+    // ring slots: tile i of an item lives in slot i mod kRing of its ring
+    int vs_prev = kRing - 1;  // V slot of tile t-1 (read by this step's P.V)
+    int vs_tgt = kVAhead;     // V slot of tile t + kVAhead (requested in this step)
+    int ks_cur = 0;           // K slot of tile t
+    int ks_tgt = kKAhead;     // K slot of tile t + kKAhead (requested in this step)
+    auto next_slot = [](int x) { return x + 1 == kRing ? 0 : x + 1; };
+    // pieces that may stay in flight over a step's barrier: everything requested after K(t+1) and
+    // after V(t), which the next step reads (a step issues its 4 K pieces before its 4 V pieces)
+    constexpr int kStepWait = (4 + 8 * (kKAhead - 1)) < 8 * kVAhead ? (4 + 8 * (kKAhead - 1)) : 8 * kVAhead;
+    static_assert(kStepWait == (kRing == 3 ? 8 : 16), "counted wait");
     K1_STAMP(2);  // kernel start .. first step (Q load, first two tiles)
     // Every wave runs the same number of steps (nsteps), one barrier each, but walks them in its
     // own phases -- separate loops, so that each hot loop is one straight body whose registers
@@ -1201,36 +1231,40 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     int t = 0;
     // end of a step: publish tile t+1 (written during this step), rotate the rings
     auto step_end = [&]() {
-        // the wave's 8 pieces of this step (K of tile t+2, V of tile t+1) may stay in flight, the 8
-        // of the step before (K of t+1, V of t: read in the next step) must have landed; hipcc does
-        // not count LDS-DMA issued from asm, so __syncthreads() below is a bare s_barrier
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the wave's pieces of this step (and, rings of 4, of the step before) may stay in flight;
+        // K of t+1 and V of t, read in the next step, must have landed; hipcc does not count
+        // LDS-DMA issued from asm, so __syncthreads() below is a bare s_barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStepWait) : "memory");
         __syncthreads();
         K1_STAMP(11);  // barrier
 #ifdef NVLLM_K1_STAMPS
         seg_sum[15] += 1;
 #endif
-        const int x = vs_prev;
-        vs_prev = vs_cur;
-        vs_cur = vs_next;
-        vs_next = x;
-        const int y = ks_cur;
-        ks_cur = ks_n1;
-        ks_n1 = ks_n2;
-        ks_n2 = y;
+        vs_prev = next_slot(vs_prev);
+        vs_tgt = next_slot(vs_tgt);
+        ks_cur = next_slot(ks_cur);
+        ks_tgt = next_slot(ks_tgt);
         ++t;
         if constexpr (PAGED) {
             pg_s0 = pg_s1;
             pg_s1 = pg_s2;
-            pg_s2 = dma_id(t + 3);
+            if constexpr (kRing == 4) {
+                pg_s2 = pg_s3;
+                pg_s3 = dma_id(t + 4);
+            } else {
+                pg_s2 = dma_id(t + 3);
+            }
         }
     };
-    // staging of a step, all at once (steps this wave has no keys for): K of tile t+2, V of tile t+1
+    // PAGED: ids of the blocks this step's requests go to (pg_s0 = tile t+1, ...)
+    auto k_id = [&]() { return kKAhead == 3 ? pg_s2 : pg_s1; };
+    auto v_id = [&]() { return kVAhead == 2 ? pg_s1 : pg_s0; };
+    // staging of a step, all at once (steps this wave has no keys for): K of tile t + kKAhead, V of tile t + kVAhead
     auto stage_step = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(t + 2, ks_n2, 0, j, pg_s1);
+        for (int j = 0; j < 4; ++j) dma_piece(t + kKAhead, ks_tgt, 0, j, k_id());
 #pragma unroll
-        for (int j = 4; j < 8; ++j) dma_piece(t + 1, 0, vs_next, j, pg_s0);
+        for (int j = 4; j < 8; ++j) dma_piece(t + kVAhead, 0, vs_tgt, j, v_id());
     };
     // ... or dealt out over the MFMA gaps of the pipelined bodies, into slices that issue no
     // fragment reads: the K pieces in the first four staging positions of the QK^T slot, the V
@@ -1240,8 +1274,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
 #else
     auto st_pos = [&](int p, int base) {
         if (p < 4) {
-            if (base == 0) dma_piece(t + 2, ks_n2, 0, p, pg_s1);
-            else dma_piece(t + 1, 0, vs_next, 4 + p, pg_s0);
+            if (base == 0) dma_piece(t + kKAhead, ks_tgt, 0, p, k_id());
+            else dma_piece(t + kVAhead, 0, vs_tgt, 4 + p, v_id());
         }
     };
 #endif
@@ -1289,7 +1323,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_qk(pB, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_qk(pA, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + 2, ks_n2, 0, k >> 2, pg_s1);
+                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + kKAhead, ks_tgt, 0, k >> 2, k_id());
 #endif
                  },
                  [&](int j) { read_v(vs_prev, j); });
@@ -1304,7 +1338,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
                      if constexpr (k & 1) valu_pv(nB_, B, ic<kDealDualB>{}, ic<(k >> 1)>{});
                      else valu_pv(nA_, A, ic<kDealDualA>{}, ic<(k >> 1)>{});
 #ifndef K1_ABL_NOSTAGE
-                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + 1, 0, vs_next, 4 + (k >> 2), pg_s0);
+                     if constexpr ((k & 3) == 3 && (k >> 2) < 4) dma_piece(t + kVAhead, 0, vs_tgt, 4 + (k >> 2), v_id());
 #endif
                  },
                  no_rd);
@@ -1386,7 +1420,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             // keep their order) and leaves as whole 256-byte rows, four per store instruction:
             // stored straight from the accumulator layout every instruction would touch 32 rows,
             // 16 bytes each
-            unsigned char *stg = lds + kLdsBytes + wave * kOStage;
+            unsigned char *stg = lds + kOStageBase + wave * kOStage;
             static_for<16>([&](auto X) {
                 constexpr int dt = decltype(X)::value >> 2, i = decltype(X)::value & 3;
                 float a4[4];
@@ -1437,8 +1471,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
         clear_item(I1);
         clear_item(J0);
         clear_item(J1);
-        vs_prev = 2, vs_cur = 0, vs_next = 1;
-        ks_cur = 0, ks_n1 = 1, ks_n2 = 2;
+        vs_prev = kRing - 1, vs_tgt = kVAhead;
+        ks_cur = 0, ks_tgt = kKAhead;
         t = 0;
         K1_STAMP(2);  // kernel start (or the epilogue's end) .. first step (Q load, first two tiles)
         // ---- phase 1: both blocks, alternating the two score register sets.  The (empty) pending items

@@ -94,6 +94,19 @@ print("VALU write -> MFMA operand within 2 instructions:", len(haz))
 for h in haz[:6]: print(h)
 print("compiler uses of a[0:223] outside asm:", len(bad))
 for n, l in bad[:10]: print(n, l)
+# vector-register spills per kernel (the metadata lists .name before .vgpr_spill_count? no fixed
+# order: collect both per kernel entry)
+entry = {}
+for line in open(sys.argv[1]):
+    t = line.strip()
+    if t.startswith('- .agpr_count') or t.startswith('- .args'):
+        entry = {}
+    m = re.match(r'\.?-? ?\.(name|vgpr_spill_count):\s+(\S+)', t)
+    if m:
+        entry[m.group(1)] = m.group(2)
+        if len(entry) == 2:
+            print("spills %s %s" % (entry['vgpr_spill_count'], entry['name']))
+            entry = {}
 for key in ('.vgpr_spill_count', '.sgpr_spill_count', '.private_segment_fixed_size', '.vgpr_count', '.agpr_count', '.sgpr_count'):
     for line in open(sys.argv[1]):
         if key in line: print(line.strip())

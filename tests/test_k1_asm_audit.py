@@ -6,8 +6,8 @@ inline asm, which hipcc neither schedules around nor pads hazards for.  The audi
 gfx950 assembly and requires: no compiler-generated use of the owned AGPR range outside the asm
 statements, no scratch (spill) traffic inside the step loops, no VALU write of an MFMA operand
 within the two instructions in front of an MFMA statement, no VALU-written SGPR read by an LDS-DMA
-load within 5 wait states.  Vector-register spills: none in any variant but the chained paged one
-(opt-in, NVLLM_K1_CHAIN), which keeps a few lane constants in scratch BETWEEN items."""
+load within 5 wait states.  Vector-register spills: none in the one-item-per-workgroup variants;
+the chained ones (CHAIN) keep a few lane constants in scratch BETWEEN items."""
 import os
 import subprocess
 import sys
@@ -31,7 +31,11 @@ def test_k1_isa_audit(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     text = r.stdout
     assert "inside step loops: 0" in text
-    spills = [int(l.split(":")[1]) for l in text.splitlines() if l.startswith(".vgpr_spill_count")]
+    spills = {l.split()[2]: int(l.split()[1]) for l in text.splitlines() if l.startswith("spills ")}
     assert len(spills) == 7, text                   # merge kernel + six instantiations of the K1 kernel
-    assert sorted(spills)[:-1] == [0] * 6, spills   # at most one variant spills at all ...
-    assert max(spills) <= 24, spills                # ... and that one only a handful of registers
+    for name, n in spills.items():
+        chained = "flash_attn_mfma_kernel" in name and name.split("flash_attn_mfma_kernelI")[1].startswith(
+            ("Lb1ELb0ELb0ELb1", "Lb1ELb1ELb0ELb1"))
+        # the chained variants keep a few lane constants in scratch BETWEEN items (never inside the
+        # step loops: asserted above); everything else does not spill at all
+        assert n <= (24 if chained else 0), (name, n)
