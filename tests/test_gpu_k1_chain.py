@@ -113,3 +113,24 @@ def test_dense_chain_is_the_default_once_there_are_four_rounds_of_items(dev, pol
     policy.setenv("NVLLM_K1_CHAIN", "0")
     plain = _dense(dev, q, k, v)
     assert torch.equal(default, plain)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_chain_random_shapes(dev, policy, seed):
+    # random batch / length / head shapes, forced chain lengths: bit-identical to one workgroup per item
+    rng = np.random.default_rng(9300 + seed)
+    B = int(rng.integers(2, 9))
+    Sq = int(rng.integers(1, 900))
+    Skv = Sq if rng.random() < 0.7 else int(rng.integers(1, 900))
+    Hkv = int(rng.choice([1, 2, 4, 8]))
+    Hq = Hkv * int(rng.choice([1, 2, 4]))
+    g = torch.Generator(device="cpu").manual_seed(9300 + seed)
+    q = torch.randn((B, Sq, Hq, 128), generator=g).to(dev, torch.bfloat16)
+    k = torch.randn((B, Skv, Hkv, 128), generator=g).to(dev, torch.bfloat16)
+    v = torch.randn((B, Skv, Hkv, 128), generator=g).to(dev, torch.bfloat16)
+    policy.setenv("NVLLM_K1_CHAIN", "0")
+    want = _dense(dev, q, k, v)
+    assert torch.isfinite(want.float()).all()
+    for chain in (2, int(rng.integers(3, 9))):
+        policy.setenv("NVLLM_K1_CHAIN", str(chain))
+        assert torch.equal(_dense(dev, q, k, v), want), (B, Sq, Skv, Hq, Hkv, chain)
