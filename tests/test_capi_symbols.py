@@ -140,7 +140,7 @@ def test_product_build_defines_no_lab_switch():
     spec = importlib.util.spec_from_file_location("nvllm_build", os.path.join(ROOT, "nano-vllm-rs_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    banned = re.compile(r"K1_ABL_|NVLLM_K1_STAMPS|NVLLM_K1_LAB|K1_FINE|K1_RT|K1_DBG_")
+    banned = re.compile(r"K1_ABL_|NVLLM_K1_STAMPS|NVLLM_K1_LAB|K1_FINE|K1_RT|K1_DBG_|K1_DEV_|K1_STAMP_SETUP")
     assert not any(banned.search(f) for f in b.FLAGS), b.FLAGS
     assert not banned.search(open(os.path.join(ROOT, "rust", "build.rs")).read())
     assert not banned.search(open(os.path.join(ROOT, "nano-vllm-rs_amd", "build.py")).read())
