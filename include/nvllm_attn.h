@@ -160,6 +160,9 @@ size_t nvllm_paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int nu
  *   0 = decode kernel (bandwidth, MFMA 16x16x32, split-K)      csrc/paged_attn.hip
  *   1 = prefill kernel over the cache (MFMA 32x32x16, K1 paged) csrc/flash_attn_mfma.hip
  *   2 = generic kernel (any head_dim / block_size / f32)
+ *   3 = mid kernel: 49..128 query rows per kv head on large launches (two workgroups per CU;
+ *       at least four (sequence, kv head) units per CU and either <= 64 rows or no context beyond
+ *       1024 tokens)                                                csrc/paged_attn_mid.hip
  * dtype 0 bf16, 1 f32.  Negative nvllm_status on invalid dimensions. */
 int nvllm_paged_attn_path(int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
                           int head_dim, int block_size, int max_blocks_per_seq,
@@ -257,7 +260,8 @@ int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64
  * that is otherwise taken from the launch shape.  `name` is one of
  * NVLLM_PAGED_MAX_ROWS, NVLLM_PAGED_SPLITS, NVLLM_PAGED_WAVE_TARGET,
  * NVLLM_PAGED_NT, NVLLM_PAGED_HPB, NVLLM_PAGED_FLASH, NVLLM_K1_PAIRING (0
- * balanced / 1 adjacent), NVLLM_K1_PACK, NVLLM_K1_KSPLIT, NVLLM_K1_CHAIN.  Environment variables
+ * balanced / 1 adjacent), NVLLM_K1_PACK, NVLLM_K1_KSPLIT, NVLLM_K1_CHAIN, NVLLM_PAGED_MID (0 never / 1 whenever the
+ * shape allows / -1 by launch size).  Environment variables
  * of the same names seed the values once, at first use; no launch reads the
  * environment.  Process-wide: nvllm_paged_attn_workspace_bytes and the launch
  * both see the value in force when they are called.  _reset restores the

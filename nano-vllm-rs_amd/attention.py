@@ -118,7 +118,7 @@ def paged_attention(query, kv_cache, block_table, context_len, num_heads, num_kv
     return out
 
 
-PAGED_PATHS = ("decode", "k1_paged", "generic")
+PAGED_PATHS = ("decode", "k1_paged", "generic", "paged_mid")
 
 
 def paged_attention_path(num_seqs, num_new_tokens, num_heads, num_kv_heads, head_dim, block_size,

@@ -19,6 +19,7 @@ SOURCES = [
     "reshape_and_cache.hip",
     "qk_norm_rope_cache.hip",
     "paged_attn.hip",
+    "paged_attn_mid.hip",
     "flash_attn.hip",
     "flash_attn_mfma.hip",
 ]

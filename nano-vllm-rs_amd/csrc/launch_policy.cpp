@@ -15,7 +15,7 @@ namespace {
 
 // one relaxed atomic per field: launches and workspace queries read them without a lock and never
 // see a torn value; set / reset are serialised by g_mu
-constexpr int kNumFields = 10;
+constexpr int kNumFields = 11;
 std::atomic<int> g_values[kNumFields];
 std::once_flag g_once;
 std::mutex g_mu;
@@ -36,6 +36,7 @@ const Field kFields[] = {
     {"NVLLM_K1_PACK", &LaunchPolicy::k1_pack, -1},
     {"NVLLM_K1_KSPLIT", &LaunchPolicy::k1_ksplit, 0},
     {"NVLLM_K1_CHAIN", &LaunchPolicy::k1_chain, -1},
+    {"NVLLM_PAGED_MID", &LaunchPolicy::paged_mid, -1},
 };
 
 static_assert(sizeof(kFields) / sizeof(kFields[0]) == kNumFields, "one atomic per field");

@@ -26,6 +26,7 @@ struct LaunchPolicy {
     int k1_pairing;         // NVLLM_K1_PAIRING: 0 balanced ('b'), 1 adjacent ('a'), -1 by grid size
     int k1_pack;            // NVLLM_K1_PACK: 0 no head packing, -1 / 1 pack when the group allows
     int k1_ksplit;          // NVLLM_K1_KSPLIT: > 0 forces the key-split part count
+    int paged_mid;          // NVLLM_PAGED_MID: 0 never / 1 whenever supported / -1 by launch size (paged_attn_mid.hip)
     int k1_chain;           // NVLLM_K1_CHAIN: items per workgroup (0 / 1 = no chaining), -1 by grid size
 };
 // a snapshot by value (each field read atomically).  A workspace query and the launch it sizes see
@@ -110,8 +111,11 @@ size_t paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int num_head
                                   int max_blocks_per_seq);
 // which kernel launch_paged_attn runs for these arguments (pointers may be null in a pure query:
 // a null pointer counts as aligned)
-enum class PagedPath : int { Decode = 0, K1Paged = 1, Generic = 2 };
+enum class PagedPath : int { Decode = 0, K1Paged = 1, Generic = 2, Mid = 3 };
 PagedPath paged_attn_path(DType dt, const PagedAttnArgs &a);
+// K3b: 49..128 query rows per kv head, two workgroups per CU (paged_attn_mid.hip)
+bool paged_attn_mid_supported(DType dt, const PagedAttnArgs &a);
+hipError_t launch_paged_attn_mid(const PagedAttnArgs &a, hipStream_t stream);
 // what THIS launch needs (<= paged_attn_workspace_bytes of its shape: 0 when the generic kernel runs)
 size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a);
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream);

@@ -684,10 +684,27 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
     return (int)splits;
 }
 
+namespace {
+// 49..128 query rows per kv head: the two-workgroups-per-CU kernel (paged_attn_mid.hip) where it
+// measured faster than the prefill kernel over the cache (profiles/r03_paged_mid.txt): launches with
+// at least four (sequence, kv head) units per CU, i.e. two rounds of two workgroups -- fewer go to
+// the prefill kernel, whose key split spreads them over the chip -- and up to 64 rows (two of its four waves compute), or up to 128 rows
+// when no context is longer than 1024 tokens (fixed costs weigh most on short walks).
+bool use_mid(DType dt, const PagedAttnArgs &a) {
+    const int mode = launch_policy().paged_mid;
+    if (mode == 0 || launch_policy().paged_flash == 0 || !paged_attn_mid_supported(dt, a)) return false;
+    if (mode > 0) return true;
+    if ((int64_t)a.num_seqs * a.num_kv_heads < (int64_t)4 * device_cus()) return false;
+    const int rows = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
+    return rows <= 64 || (int64_t)a.max_blocks_per_seq * a.block_size <= 1024;
+}
+}  // namespace
+
 PagedPath paged_attn_path(DType dt, const PagedAttnArgs &a) {
     if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                              a.block_size, a.max_blocks_per_seq))
         return PagedPath::Decode;
+    if (use_mid(dt, a)) return PagedPath::Mid;
     if (launch_policy().paged_flash != 0 && flash_attn_paged_supported(dt, a)) return PagedPath::K1Paged;
     return PagedPath::Generic;
 }
@@ -772,7 +789,8 @@ hipError_t launch_paged_attn_noalloc(DType dt, const PagedAttnArgs &args, hipStr
 }
 
 size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a) {
-    if (dt != DType::BF16 || paged_attn_path(dt, a) == PagedPath::Generic) return 0;
+    const PagedPath path = paged_attn_path(dt, a);
+    if (dt != DType::BF16 || path == PagedPath::Generic || path == PagedPath::Mid) return 0;
     return paged_attn_workspace_bytes(a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                                       a.block_size, a.max_blocks_per_seq);
 }
@@ -830,6 +848,7 @@ hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t strea
         }
         return err;
     }
+    if (use_mid(dt, a)) return launch_paged_attn_mid(a, stream);
     // more query rows per kv head (chunked prefill, long verify): the prefill kernel
     // reading K/V through the block table
     if (launch_policy().paged_flash != 0 && flash_attn_paged_supported(dt, a))

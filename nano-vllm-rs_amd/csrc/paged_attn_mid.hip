@@ -1,0 +1,379 @@
+// paged_attn_mid.hip -- K3b: paged attention for 49..128 query rows per kv head when K/V streams
+// from HBM (many sequences, short chunks: speculative verify with T > 12, chunked prefill with
+// chunks of 13..32 tokens at 32Q/8KV), hand-written for gfx950.
+//
+// Same contract as the other paged kernels (reference src/attention/paged.rs:117-192, bottom-right
+// causal mask :357-381): T new tokens per sequence attend to context_lens[seq] cached keys, query
+// t at position ctx - T + t.
+//
+// Why a third kernel.  The decode kernel (paged_attn.hip) holds at most 48 rows per wave; the
+// prefill kernel over the cache (flash_attn_mfma.hip, PAGED) gives one workgroup the whole
+// 512-register file and therefore the CU: its prologue, epilogue and the hand-over between
+// workgroups (17 % of an item's life on these shapes, profiles/r03_k1_chain.txt) have nothing to
+// overlap with, and chaining items inside the workgroup only moves them around.  These shapes are
+// HBM-bound, not MFMA-bound -- so this kernel gives up the prefill kernel's software pipeline
+// (256 registers per wave, compiler-scheduled MFMA builtins, one score register set) to fit TWO
+// workgroups on a CU, and lets the hardware overlap one workgroup's fixed costs and softmax with
+// the other's streaming.
+//
+// Roofline: HBM.  Algorithmic bytes per unit (one cached token of one sequence) as in paged_attn.hip.
+//
+// Work decomposition: grid = num_seqs * Hkv workgroups (sequence fastest), 4 waves each; wave w owns
+// packed rows 32w .. 32w+31 of the kv head's R = T * G rows (row rho = token rho / G, head rho % G
+// of the group).  Key tiles of 64 tokens go HBM -> LDS by LDS-DMA exactly as in the prefill kernel
+// (wave w fetches block 4 tile + w of the sequence through a per-block buffer descriptor; the
+// bank-conflict swizzle is applied through each lane's source address), rings K x3 + V x2 = 80 KiB
+// per workgroup: step t requests V(t+1) and K(t+2); counted waits, two barriers per step.
+// Per tile and wave: S^T = K Q^T (16 x mfma_f32_32x32x16_bf16, Q^T in registers), online softmax
+// in the exp2 domain with the query row on the lane, O^T += V^T P^T (16 MFMAs, V^T by
+// ds_read_b64_tr_b16, P^T straight from the S^T accumulators).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "nvllm_kernels.hpp"
+
+namespace nvllm {
+namespace kernels {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int kD = 128;
+constexpr int kKV = 64;                  // keys per tile
+constexpr int kRow = 256;                // bytes of a K / V row in LDS
+constexpr int kTile = kKV * kRow;        // 16 KiB
+constexpr int kWaves = 4;
+constexpr int kKRing = 3, kVRing = 2;    // K is requested two tiles ahead, V one
+constexpr int kVBase = kKRing * kTile;
+constexpr int kLds = (kKRing + kVRing) * kTile;  // 80 KiB: two workgroups fill a CU's 160 KiB
+constexpr int kORow = 272, kOStage = 32 * kORow;
+static_assert(kWaves * kOStage <= kKRing * kTile, "O staging reuses the K ring");
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 r;
+    r[0] = static_cast<__bf16>(lo);
+    r[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
+    const __bf16 *__restrict__ q, const unsigned char *__restrict__ k_cache,
+    const unsigned char *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
+    const int32_t *__restrict__ context_lens, __bf16 *__restrict__ out, int T, int Hq, int Hkv,
+    int max_blocks_per_seq, unsigned num_cache_blocks, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31;  // query row within the wave's block / key row / d row
+    const int h = lane >> 5;  // lane half
+    // sequence fastest: the workgroups in flight together walk the same kv head of different sequences
+    // (measured 403 against 413 us for 256 x 2048, T = 13, with the kv head fastest)
+    const int num_seqs = gridDim.x / Hkv;
+    const int seq = blockIdx.x % num_seqs;
+    const int kvh = blockIdx.x / num_seqs;
+    const int G = Hq / Hkv;
+    const int R = T * G;
+    int ctx = context_lens[seq];
+    const int cap = max_blocks_per_seq * 16;
+    ctx = ctx < 0 ? 0 : (ctx > cap ? cap : ctx);
+    const int nt = (ctx + kKV - 1) / kKV;
+    const int32_t *table = block_tables + (int64_t)seq * max_blocks_per_seq;
+    auto block_id = [&](int tile) -> unsigned {
+        int bi = 4 * tile + wave;
+        bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
+        return (unsigned)table[bi];
+    };
+    unsigned id1 = block_id(1), id2 = block_id(2), id3 = block_id(3);  // the wave's blocks in tiles t+1, t+2, t+3
+
+    // this lane's query row
+    const int rho = 32 * wave + c;
+    const bool row_ok = rho < R;
+    const int t_row = row_ok ? rho / G : 0;
+    const int g_row = rho - t_row * G;
+    const int qpos = ctx - T + t_row;          // position: keys 0 .. qpos are visible
+    const bool wave_live = 32 * wave < R;      // (uniform)
+
+    // ---- staging (see flash_attn_mfma.hip): piece j = rows 16 wave + 4 j .. + 3 of the tile, lane L
+    // fetches the 16-byte chunk that the swizzle puts at position L & 15 of row L >> 4
+    const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
+    const unsigned block_bytes = 16u * row_bytes;
+    const unsigned head = (unsigned)kvh * (unsigned)(kD * 2);
+    const unsigned long long kbase = (unsigned long long)k_cache + head, vbase = (unsigned long long)v_cache + head;
+    const unsigned nrec = block_bytes - head;
+    unsigned dma_pk[4], dma_pv[4];
+    {
+        const unsigned rin = (unsigned)lane >> 4, pos = (unsigned)lane & 15u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned r = 4u * j + rin;
+            dma_pk[j] = r * row_bytes + 16u * (pos ^ (r & 15u));
+            dma_pv[j] = r * row_bytes + 16u * (pos ^ (4u * rin));
+        }
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
+    // descriptor of this kv head's rows in block `id`; a tile past the context (live = false) or an id
+    // outside the pool gets num_records = 0: the request still counts in vmcnt, but fetches nothing
+    auto desc = [&](unsigned long long base, unsigned id, bool live) -> u32x4 {
+        id = (unsigned)__builtin_amdgcn_readfirstlane((int)id);
+        const unsigned long long a = base + (unsigned long long)id * block_bytes;
+        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, (live && id < num_cache_blocks) ? nrec : 0u, 0x00020000u};
+    };
+    // this wave's 16 rows of K tile `tile` -> K ring slot `slot` (4 pieces) / of V tile -> V ring slot
+    auto request_k = [&](int tile, int slot, unsigned id) {
+        const u32x4 rk = desc(kbase, id, tile < nt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned dst = lds_base + (unsigned)(slot * kTile) + (16u * wave + 4u * j) * 256u;
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
+        }
+    };
+    auto request_v = [&](int tile, int slot, unsigned id) {
+        const u32x4 rv = desc(vbase, id, tile < nt);
+        const int rows_left = ctx - 16 * (4 * tile + wave);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned dst = lds_base + (unsigned)(kVBase + slot * kTile) + (16u * wave + 4u * j) * 256u;
+            const int r = 4 * j + (lane >> 4);
+            const unsigned off = r < rows_left ? dma_pv[j] : 0x40000000u;  // rows past the context: true zeros
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         : : "s"(dst), "v"(off), "s"(rv) : "memory");
+        }
+    };
+
+    // ---- Q^T fragments (B operand of S^T = K Q^T): lane (c, h) holds Q[row c][16 ks + 8 h .. + 7]
+    u32x4 qf[8];
+    {
+        const unsigned seq_bytes = (unsigned)T * (unsigned)Hq * (unsigned)(kD * 2);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(q + (int64_t)seq * T * Hq * kD), 0, (int)seq_bytes, 0x00020000);
+        const unsigned off = row_ok ? ((unsigned)t_row * (unsigned)Hq + (unsigned)(kvh * G + g_row)) * (unsigned)(kD * 2) + 16u * h
+                                    : 0xffffff00u;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            qf[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 32u * ks), 0, 0));
+    }
+    // "step -1": K(0), then V(0) and K(1) as every step requests V one and K two tiles ahead
+    request_k(0, 0, block_id(0));
+    request_v(0, 0, block_id(0));
+    request_k(1, 1, id1);
+
+    // ---- LDS read addresses (as in flash_attn_mfma.hip)
+    unsigned k_rd8[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) k_rd8[ks] = (unsigned)(c * kRow + 16 * ((2 * ks + h) ^ (c & 15)));
+    const int c16 = lane & 15, qq = c16 >> 2, pp = c16 & 3, g16 = lane >> 4;
+    const int v_row_in = 4 * h + qq;
+    const int v_sw = 4 * (v_row_in & 3);
+    const int v_ch_lo = 2 * (g16 & 1) + (pp >> 1);
+    unsigned v_rd[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        v_rd[dt] = (unsigned)(v_row_in * kRow + 8 * (pp & 1) + 16 * ((4 * dt + v_ch_lo) ^ v_sw));
+
+    // ---- running state: O^T of the wave's 32 rows (d tile dt in acc[dt]), row max, partial row sum
+    f32x16 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[dt][i] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // Counted waits (hipcc does not see the LDS-DMA requests): every step issues 4 V pieces, then 4 K
+    // pieces.  Before QK^T of tile t+1, K(t+1) must have landed -- everything younger (this step's 8
+    // pieces) may fly: vmcnt(8).  Before P.V of tile t, V(t) must have landed -- younger are K(t+1) and
+    // this step's 8: vmcnt(12).  Each wait is followed by a barrier (the pieces are the four waves').
+    // (the Q rows are the only loads hipcc knows of: consumed here once, or it would wait for them --
+    // and with them for every request in flight -- in front of each step's first MFMAs)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+
+    int kslot = 0, kslot_req = 2;  // K ring slot of tile t / of tile t+2
+    for (int t = 0; t < nt; ++t) {
+        const int vslot = t & 1;
+        request_v(t + 1, vslot ^ 1, id1);
+        request_k(t + 2, kslot_req, id2);
+        id1 = id2;
+        id2 = id3;
+        id3 = block_id(t + 4);
+        const unsigned char *kt = lds + kslot * kTile;
+        const unsigned char *vt = lds + kVBase + vslot * kTile;
+        kslot = kslot == kKRing - 1 ? 0 : kslot + 1;
+        kslot_req = kslot_req == kKRing - 1 ? 0 : kslot_req + 1;
+        u32x4 p[4];
+        if (wave_live) {
+            // ---- S^T = K Q^T: keys 0..31 of the tile in sa, 32..63 in sb.  The fragments of two
+            // k-steps are read while the two before them are multiplied (the order is pinned: left to
+            // itself hipcc puts every read right in front of its MFMA and waits for it there)
+            f32x16 sa, sb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sa[i] = 0.0f; sb[i] = 0.0f; }
+            u32x4 kf[2][4];  // [set][2 * (ks & 1) + key half]
+            auto read_k = [&](int set, int ks0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    kf[set][2 * i] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i]);
+                    kf[set][2 * i + 1] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i] + 32 * kRow);
+                }
+            };
+            read_k(0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) read_k((g + 1) & 1, 2 * g + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i]),
+                                                                 __builtin_bit_cast(bf16x8, qf[2 * g + i]), sa, 0, 0, 0);
+                    sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i + 1]),
+                                                                 __builtin_bit_cast(bf16x8, qf[2 * g + i]), sb, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- mask: only tiles that reach past the first query position or the context (a real
+            // branch: the asm statement keeps hipcc from turning it into 130 predicated instructions
+            // for every tile)
+            const int kv0 = t * kKV;
+            if (kv0 + kKV > ctx - T + 1) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sa[r] = (key < ctx && key <= qpos) ? sa[r] : -INFINITY;
+                    sb[r] = (key + 32 < ctx && key + 32 <= qpos) ? sb[r] : -INFINITY;
+                }
+            }
+            // ---- online softmax (exp2 domain); the row's two lane halves hold different keys
+            float mx = fmaxf(sa[0], sb[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float mc = m_safe * scale_log2e;
+            if (__any(m_new > m_run)) {  // (uniform branch: most tiles leave every row's max alone)
+                const float alpha = fast_exp2(m_run * scale_log2e - mc);  // exp2(-inf) = 0 for a fresh row
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
+                m_run = m_new;
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 32; e += 2) {
+                const float s0 = e < 16 ? sa[e & 15] : sb[e & 15];
+                const float s1 = e < 16 ? sa[(e + 1) & 15] : sb[(e + 1) & 15];
+                const float y0 = fast_exp2(__builtin_fmaf(s0, scale_log2e, -mc));
+                const float y1 = fast_exp2(__builtin_fmaf(s1, scale_log2e, -mc));
+                psum += y0 + y1;
+                p[e >> 3][(e & 7) >> 1] = pack_bf16x2(y0, y1);
+            }
+            l_run += psum;
+        }
+        // V(t) has landed (all four waves' pieces)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __syncthreads();
+        if (wave_live) {
+            // ---- O^T += V^T P^T, the four fragments of a d tile read while the d tile before is multiplied
+            s16x8 vf[2][4];
+            auto read_v = [&](int set, int dt) {
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    const unsigned char *p0 = vt + v_rd[dt] + sp * 16 * kRow;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kRow));
+                    vf[set][sp] = s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+            };
+            read_v(0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                if (dt < 3) read_v((dt + 1) & 1, dt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[dt & 1][sp]),
+                                                                      __builtin_bit_cast(bf16x8, p[sp]), acc[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // K(t+1) has landed
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T lane (c, h) holds O[row c][32 dt + 8 i + 4 h + (0..3)] in acc[dt][4 i .. 4 i + 3];
+    // through a wave-private LDS image (the rings are free), out as whole 256-byte rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the last tile (they fetch nothing) are in
+    __syncthreads();
+    if (!wave_live) return;
+    float l = l_run + __shfl_xor(l_run, 32);
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    unsigned char *stg = lds + wave * kOStage;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 w;
+            w[0] = pack_bf16x2(acc[dt][4 * i] * inv, acc[dt][4 * i + 1] * inv);
+            w[1] = pack_bf16x2(acc[dt][4 * i + 2] * inv, acc[dt][4 * i + 3] * inv);
+            *reinterpret_cast<u32x2 *>(stg + c * kORow + (32 * dt + 8 * i + 4 * h) * 2) = w;
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int ri = 4 * r + (lane >> 4);
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(stg + ri * kORow + (lane & 15) * 16);
+        const int orho = 32 * wave + ri;
+        if (orho < R) {
+            const int ot = orho / G, og = orho - ot * G;
+            *reinterpret_cast<u32x4 *>(out + (((int64_t)seq * T + ot) * Hq + kvh * G + og) * kD + (lane & 15) * 8) = x;
+        }
+    }
+}
+
+}  // namespace
+
+// Shapes the kernel takes: bf16, head_dim 128, block 16, 49..128 query rows per kv head.  Whether
+// it is the one to run is the dispatcher's decision (enough units that K/V streams from HBM in
+// several rounds of workgroups; fewer go to the prefill kernel and its key split).
+bool paged_attn_mid_supported(DType dt, const PagedAttnArgs &a) {
+    if (dt != DType::BF16 || a.head_dim != kD || a.block_size != 16) return false;
+    if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0 || a.num_kv_heads >= (1 << 15)) return false;
+    const int64_t rows = (int64_t)a.num_new_tokens * (a.num_heads / a.num_kv_heads);
+    if (rows <= 48 || rows > 128) return false;
+    if (a.num_seqs <= 0 || (int64_t)a.num_seqs * a.num_kv_heads > 0x7fffffffLL) return false;
+    if (a.max_blocks_per_seq <= 0 || a.max_blocks_per_seq > (1 << 26)) return false;
+    if (a.num_cache_blocks <= 0 || a.num_cache_blocks > (int64_t)0x7fffffff) return false;
+    if ((int64_t)a.num_new_tokens * a.num_heads * kD * 2 >= (int64_t)1 << 31) return false;
+    const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    return al(a.q) && al(a.k_cache) && al(a.v_cache) && al(a.out);
+}
+
+hipError_t launch_paged_attn_mid(const PagedAttnArgs &a, hipStream_t stream) {
+    const dim3 grid((unsigned)(a.num_seqs * a.num_kv_heads)), block(64 * kWaves);
+    paged_attn_mid_kernel<<<grid, block, 0, stream>>>(
+        static_cast<const __bf16 *>(a.q), static_cast<const unsigned char *>(a.k_cache),
+        static_cast<const unsigned char *>(a.v_cache), a.block_tables, a.context_lens,
+        static_cast<__bf16 *>(a.out), a.num_new_tokens, a.num_heads, a.num_kv_heads, a.max_blocks_per_seq,
+        (unsigned)a.num_cache_blocks, a.scale * 1.4426950408889634f);
+    return hipGetLastError();
+}
+
+}  // namespace kernels
+}  // namespace nvllm

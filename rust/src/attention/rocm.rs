@@ -265,6 +265,7 @@ pub enum PagedPath {
     Decode,
     K1Paged,
     Generic,
+    Mid,
 }
 
 #[allow(clippy::too_many_arguments)]
@@ -278,6 +279,7 @@ pub fn paged_attention_path(n: usize, t: usize, hq: usize, hkv: usize, d: usize,
         0 => Ok(PagedPath::Decode),
         1 => Ok(PagedPath::K1Paged),
         2 => Ok(PagedPath::Generic),
+        3 => Ok(PagedPath::Mid),
         e => check(e).map(|_| PagedPath::Generic),
     }
 }

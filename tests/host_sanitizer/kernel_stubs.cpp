@@ -13,6 +13,8 @@ hipError_t launch_reshape_and_cache(const void *, const void *, void *, void *, 
 hipError_t launch_gather_blocks(const void *, const int32_t *, void *, int64_t, int64_t, int64_t,
                                 hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_qk_norm_rope_cache(DType, const QkNormRopeCacheArgs &, hipStream_t) { return hipErrorNoDevice; }
+bool paged_attn_mid_supported(DType, const PagedAttnArgs &) { return false; }
+hipError_t launch_paged_attn_mid(const PagedAttnArgs &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_validate_tables(const int32_t *, const int32_t *, int, int, int, int64_t, int32_t *,
                                   hipStream_t) { return hipErrorNoDevice; }
 bool paged_attn_fast_path(DType, int, int, int, int, int, int, int) { return false; }
