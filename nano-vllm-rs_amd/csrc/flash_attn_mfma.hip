@@ -418,7 +418,9 @@ static_assert(offsetof(KArgs, scale_log2e) == 64 && offsetof(KArgs, block_tables
               "KArgs mirrors the kernel's parameter list");
 typedef const __attribute__((address_space(4))) KArgs *KArgsPtr;
 
-template <bool CAUSAL, bool PAGED, bool KSPLIT, bool CHAIN>
+// NT (paged only) = the K/V requests carry the non-temporal hint: the launch reads more K/V than the
+// Infinity Cache holds, each byte once.
+template <bool CAUSAL, bool PAGED, bool KSPLIT, bool CHAIN, bool NT = false>
 __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
     __bf16 *__restrict__ o, float *__restrict__ lse, int Sq, int Skv_arg, int Hq, int Hkv,
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     static_assert(CAUSAL || !PAGED, "the paged variant is causal");
     static_assert(!KSPLIT || PAGED, "the key split is wired for the paged variant");
     static_assert(!CHAIN || !KSPLIT, "a key-split launch has fewer workgroups than CUs: nothing to chain");
+    static_assert(PAGED || !NT, "the dense kernel's K/V is re-read by the other heads' workgroups: no hint");
     constexpr int kRing = ring_depth(PAGED, CHAIN);          // K and V ring slots
     constexpr int kKAhead = kRing - 1, kVAhead = kRing - 2;  // step t requests K(t + kKAhead), V(t + kVAhead)
     constexpr int kKBase = kRing * kVTile;
@@ -804,14 +807,22 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             u32x4 rs = pg_desc(j < 4 ? pg_kbase : pg_vbase, sid);
             if (settle) asm volatile("s_nop 4" : "+s"(dst));
             if (j < 4) {
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
+                if constexpr (NT)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
             } else {
                 const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
                 const int r = 4 * (j & 3) + (lane >> 4);
                 const unsigned off = r < rows_left ? dma_pv[j & 3] : kPgOutOfBlock;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(off), "s"(rs) : "memory");
+                if constexpr (NT)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
             }
         } else {
             u32x4 rs = j < 4 ? dma_krs : dma_vrs;
@@ -1804,6 +1815,11 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
     auto o = static_cast<__bf16 *>(a.out);
     const int parts = paged_ksplit_parts(a, g);
     const size_t need = (size_t)a.num_seqs * g.units * g.pairs * parts * kSplitSlotBytes;
+    // non-temporal K/V requests unless the K/V the tables can reach fits the 256 MiB Infinity Cache
+    // anyway (the decode kernel's rule); NVLLM_PAGED_NT forces either
+    const int64_t reach = (int64_t)a.num_seqs * a.max_blocks_per_seq * 2 * 16 * a.num_kv_heads * (kD * 2);
+    const int nt_forced = launch_policy().paged_nt;
+    const bool nt = nt_forced >= 0 ? nt_forced != 0 : reach > ((int64_t)256 << 20);
 #ifndef K1_DEV_ONLY_CHAIN
     if (parts > 1) {
         // checked against flash_attn_paged_workspace_bytes by the C ABI (same policy, same arithmetic)
@@ -1811,7 +1827,9 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
             return hipErrorInvalidValue;
         auto ws = static_cast<unsigned char *>(a.workspace);
         const dim3 grid((unsigned)(g.pairs * g.units * a.num_seqs), 1u, (unsigned)parts);
-        flash_attn_mfma_kernel<true, true, true, false><<<grid, block, 0, stream>>>(
+        auto kern = nt ? flash_attn_mfma_kernel<true, true, true, false, true>
+                       : flash_attn_mfma_kernel<true, true, true, false, false>;
+        kern<<<grid, block, 0, stream>>>(
             q, kc, vc, o, nullptr, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
             pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, ws,
             g.gsh, a.num_seqs, 0, 0);
@@ -1839,7 +1857,9 @@ hipError_t launch_flash_attn_paged(const PagedAttnArgs &a, hipStream_t stream) {
 #ifdef K1_DEV_ONLY_CHAIN
     return hipErrorUnknown;
 #else
-    flash_attn_mfma_kernel<true, true, false, false><<<grid, block, 0, stream>>>(
+    auto kern = nt ? flash_attn_mfma_kernel<true, true, false, false, true>
+                   : flash_attn_mfma_kernel<true, true, false, false, false>;
+    kern<<<grid, block, 0, stream>>>(
         q, kc, vc, o, lse_arg, a.num_new_tokens, 0, a.num_heads, a.num_kv_heads, g.num_q_tiles,
         pair_adjacent, scale_log2e, a.block_tables, a.context_lens, a.max_blocks_per_seq, pool, nullptr,
         g.gsh, a.num_seqs, 0, 0);

@@ -67,6 +67,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, r);
 }
 
+// NT = K/V requests carry the non-temporal hint (read once: do not keep them in L2 / Infinity Cache)
+template <bool NT>
 __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
     const __bf16 *__restrict__ q, const unsigned char *__restrict__ k_cache,
     const unsigned char *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
@@ -136,8 +138,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned dst = lds_base + (unsigned)(slot * kTile) + (16u * wave + 4u * j) * 256u;
-            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                         : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
+            if constexpr (NT)
+                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
+            else
+                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
         }
     };
     auto request_v = [&](int tile, int slot, unsigned id) {
@@ -148,8 +154,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
             unsigned dst = lds_base + (unsigned)(kVBase + slot * kTile) + (16u * wave + 4u * j) * 256u;
             const int r = 4 * j + (lane >> 4);
             const unsigned off = r < rows_left ? dma_pv[j] : 0x40000000u;  // rows past the context: true zeros
-            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                         : : "s"(dst), "v"(off), "s"(rv) : "memory");
+            if constexpr (NT)
+                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
+            else
+                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
         }
     };
 
@@ -367,7 +377,13 @@ bool paged_attn_mid_supported(DType dt, const PagedAttnArgs &a) {
 
 hipError_t launch_paged_attn_mid(const PagedAttnArgs &a, hipStream_t stream) {
     const dim3 grid((unsigned)(a.num_seqs * a.num_kv_heads)), block(64 * kWaves);
-    paged_attn_mid_kernel<<<grid, block, 0, stream>>>(
+    // non-temporal requests unless the K/V the tables can reach fits the 256 MiB Infinity Cache anyway
+    // (the decode kernel's rule, paged_attn.hip); NVLLM_PAGED_NT forces either
+    const int64_t reach = (int64_t)a.num_seqs * a.max_blocks_per_seq * 2 * 16 * a.num_kv_heads * (kD * 2);
+    const int nt_forced = launch_policy().paged_nt;
+    const bool nt = nt_forced >= 0 ? nt_forced != 0 : reach > ((int64_t)256 << 20);
+    auto kern = nt ? paged_attn_mid_kernel<true> : paged_attn_mid_kernel<false>;
+    kern<<<grid, block, 0, stream>>>(
         static_cast<const __bf16 *>(a.q), static_cast<const unsigned char *>(a.k_cache),
         static_cast<const unsigned char *>(a.v_cache), a.block_tables, a.context_lens,
         static_cast<__bf16 *>(a.out), a.num_new_tokens, a.num_heads, a.num_kv_heads, a.max_blocks_per_seq,
