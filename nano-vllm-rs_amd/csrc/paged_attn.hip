@@ -688,7 +688,7 @@ namespace {
 // 49..128 query rows per kv head: the two-workgroups-per-CU kernel (paged_attn_mid.hip) where it
 // measured faster than the prefill kernel over the cache (profiles/r03_paged_mid.txt): launches with
 // at least four (sequence, kv head) units per CU, i.e. two rounds of two workgroups -- fewer go to
-// the prefill kernel, whose key split spreads them over the chip -- and up to 64 rows (two of its four waves compute), or up to 128 rows
+// the prefill kernel, whose key split spreads them over the chip -- and up to 96 rows (three of its four waves compute), or up to 128 rows
 // when no context is longer than 1024 tokens (fixed costs weigh most on short walks).
 bool use_mid(DType dt, const PagedAttnArgs &a) {
     const int mode = launch_policy().paged_mid;
@@ -696,11 +696,12 @@ bool use_mid(DType dt, const PagedAttnArgs &a) {
     if (mode > 0) return true;
     if ((int64_t)a.num_seqs * a.num_kv_heads < (int64_t)4 * device_cus()) return false;
     const int rows = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
-    return rows <= 64 || (int64_t)a.max_blocks_per_seq * a.block_size <= 1024;
+    return rows <= 96 || (int64_t)a.max_blocks_per_seq * a.block_size <= 1024;
 }
 }  // namespace
 
 PagedPath paged_attn_path(DType dt, const PagedAttnArgs &a) {
+    if (launch_policy().paged_mid > 0 && use_mid(dt, a)) return PagedPath::Mid;  // forced: also for 33..48 rows
     if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                              a.block_size, a.max_blocks_per_seq))
         return PagedPath::Decode;
@@ -797,6 +798,7 @@ size_t paged_attn_launch_workspace_bytes(DType dt, const PagedAttnArgs &a) {
 
 hipError_t launch_paged_attn(DType dt, const PagedAttnArgs &a, hipStream_t stream) {
     if (a.num_seqs <= 0) return hipSuccess;
+    if (launch_policy().paged_mid > 0 && use_mid(dt, a)) return launch_paged_attn_mid(a, stream);
     if (paged_attn_fast_path(dt, a.num_seqs, a.num_new_tokens, a.num_heads, a.num_kv_heads, a.head_dim,
                              a.block_size, a.max_blocks_per_seq)) {
         const int splits = paged_attn_num_splits(a.num_seqs, a.num_kv_heads, a.max_blocks_per_seq);

@@ -366,7 +366,8 @@ bool paged_attn_mid_supported(DType dt, const PagedAttnArgs &a) {
     if (dt != DType::BF16 || a.head_dim != kD || a.block_size != 16) return false;
     if (a.num_kv_heads <= 0 || a.num_heads % a.num_kv_heads != 0 || a.num_kv_heads >= (1 << 15)) return false;
     const int64_t rows = (int64_t)a.num_new_tokens * (a.num_heads / a.num_kv_heads);
-    if (rows <= 48 || rows > 128) return false;
+    // (33..48 rows are the decode kernel's by default; NVLLM_PAGED_MID=1 sends them here for comparison)
+    if (rows <= (launch_policy().paged_mid > 0 ? 32 : 48) || rows > 128) return false;
     if (a.num_seqs <= 0 || (int64_t)a.num_seqs * a.num_kv_heads > 0x7fffffffLL) return false;
     if (a.max_blocks_per_seq <= 0 || a.max_blocks_per_seq > (1 << 26)) return false;
     if (a.num_cache_blocks <= 0 || a.num_cache_blocks > (int64_t)0x7fffffff) return false;

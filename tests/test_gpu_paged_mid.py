@@ -63,8 +63,9 @@ def test_mid_kernel_agrees_with_the_prefill_kernel_and_is_chosen_by_size(dev, po
     assert path(8, T) == "k1_paged"                    # too few units: the prefill kernel and its key split
     assert path(N, 4) == "decode"                      # 16 rows
     assert path(N, 33) == "k1_paged"                   # 132 rows
-    assert path(N, 24, 64) == "paged_mid"              # 96 rows, no context beyond 1024 tokens
-    assert path(N, 24, 128) == "k1_paged"              # 96 rows, long contexts
+    assert path(N, 24, 128) == "paged_mid"             # 96 rows
+    assert path(N, 28, 64) == "paged_mid"              # 112 rows, no context beyond 1024 tokens
+    assert path(N, 28, 128) == "k1_paged"              # 112 rows, long contexts
     assert nv.capi.lib().nvllm_paged_attn_workspace_bytes(N, T, Hq, Hkv, D, bs, mb) == 0
     mid = _run(dev, q, kc, vc, tables, ctx_lens, scale)
     policy.setenv("NVLLM_PAGED_MID", 0)
