@@ -192,6 +192,32 @@ def test_k1_over_the_cache_on_the_config5_pool(dev, T):
     assert t_big <= 1.2 * t_small, (t_big, t_small)
 
 
+def test_mid_kernel_on_the_config5_pool(dev, policy):
+    """The mid kernel (csrc/paged_attn_mid.hip, 49..128 rows per kv head on large launches) against
+    the same 64 GiB caches: block addresses are 64-bit there too.  Forced (32 sequences are fewer than
+    its dispatch rule asks for); oracle on sampled sequences, float32 formula on all."""
+    N, ctx, pool, T = 32, 4096, 2 * 1024 * 1024, 16
+    policy.setenv("NVLLM_PAGED_MID", 1)
+    assert nv.paged_attention_path(N, T, Hq, Hkv, D, bs, ctx // bs, pool) == "paged_mid"
+    case = _long_case(dev, N, ctx, pool, 700, T=T)
+    case["context_lens"] = torch.tensor([ctx - 13 * (i % 7) for i in range(N)], dtype=torch.int32, device=dev)
+    ctxs = case["context_lens"].cpu().tolist()
+    assert int(case["tables_np"].max()) > 2_000_000
+    got = _launch(case, T).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    kc, vc = case["caches"][0]
+    outs = []
+    sample = [0, 13, N - 1]
+    for i in sample:
+        idx = torch.from_numpy(case["tables_np"][i].astype(np.int64)).to(dev)
+        outs.append(oracle.paged_attention(case["q"][i:i + 1].float().cpu().numpy(), kc[idx].float().cpu().numpy(),
+                                           vc[idx].float().cpu().numpy(), list(range(ctx // bs)), bs, ctxs[i],
+                                           Hq, Hkv, D, SCALE))
+    assert_attention_close(got[sample], np.concatenate(outs, 0))
+    ref = torch.cat([_f32_reference(case, i, ctxs[i]) for i in range(N)], 0).cpu().numpy()
+    assert_attention_close(got, ref)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("T", [1, 4])
 def test_kv_head_sharded_slices_through_the_hip_path(dev, policy, world, T):
