@@ -12,6 +12,8 @@ nb = N * nblk
 kc = torch.randn((nb, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
 vc = torch.randn((nb, bs, Hkv, D), device=dev, dtype=torch.bfloat16)
 bt = torch.randperm(nb).to(torch.int32).reshape(N, nblk).to(dev)
+if os.environ.get('SWEEP_HOT_BLOCKS'):   # every table entry among the first few blocks: K/V come from L2 (what is left is not HBM time)
+    bt = bt % int(os.environ['SWEEP_HOT_BLOCKS'])
 cl = torch.full((N,), ctx, dtype=torch.int32, device=dev)
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
