@@ -160,9 +160,9 @@ size_t nvllm_paged_attn_workspace_bytes(int num_seqs, int num_new_tokens, int nu
  *   0 = decode kernel (bandwidth, MFMA 16x16x32, split-K)      csrc/paged_attn.hip
  *   1 = prefill kernel over the cache (MFMA 32x32x16, K1 paged) csrc/flash_attn_mfma.hip
  *   2 = generic kernel (any head_dim / block_size / f32)
- *   3 = mid kernel: 49..128 query rows per kv head on large launches (two workgroups per CU;
- *       at least four (sequence, kv head) units per CU and either <= 64 rows or no context beyond
- *       1024 tokens)                                                csrc/paged_attn_mid.hip
+ *   3 = mid kernel: 49..128 query rows per kv head (two workgroups per CU): up to 64 rows from
+ *       1.5 (sequence, kv head) units per CU, up to 96 rows from 3, up to 128 rows from 4 units per
+ *       CU when no context exceeds 2048 tokens                      csrc/paged_attn_mid.hip
  * dtype 0 bf16, 1 f32.  Negative nvllm_status on invalid dimensions. */
 int nvllm_paged_attn_path(int num_seqs, int num_new_tokens, int num_heads, int num_kv_heads,
                           int head_dim, int block_size, int max_blocks_per_seq,

@@ -686,17 +686,22 @@ int paged_attn_num_splits(int num_seqs, int num_kv_heads, int max_blocks_per_seq
 
 namespace {
 // 49..128 query rows per kv head: the two-workgroups-per-CU kernel (paged_attn_mid.hip) where it
-// measured faster than the prefill kernel over the cache (profiles/r03_paged_mid.txt): launches with
-// at least four (sequence, kv head) units per CU, i.e. two rounds of two workgroups -- fewer go to
-// the prefill kernel, whose key split spreads them over the chip -- and up to 96 rows (three of its four waves compute), or up to 128 rows
-// when no context is longer than 1024 tokens (fixed costs weigh most on short walks).
+// measured faster than the prefill kernel over the cache (profiles/r03_paged_mid.txt, 32Q/8KV):
+//   from 1.5 (sequence, kv head) units per CU: up to 64 rows (48 x 2048 T = 16: 78 against 96 us);
+//   from 3 units per CU: up to 96 rows (three of its four waves compute);
+//   from 4 units per CU, i.e. two rounds of two workgroups: up to 128 rows when no context is longer
+//   than 2048 tokens (with all four waves computing on longer walks the two kernels are level).
+// Fewer units go to the prefill kernel, whose key split spreads them over the chip (16 x 2048: 38
+// against 49 us).
 bool use_mid(DType dt, const PagedAttnArgs &a) {
     const int mode = launch_policy().paged_mid;
     if (mode == 0 || launch_policy().paged_flash == 0 || !paged_attn_mid_supported(dt, a)) return false;
     if (mode > 0) return true;
-    if ((int64_t)a.num_seqs * a.num_kv_heads < (int64_t)4 * device_cus()) return false;
+    const int64_t units = (int64_t)a.num_seqs * a.num_kv_heads, cus = device_cus();
     const int rows = a.num_new_tokens * (a.num_heads / a.num_kv_heads);
-    return rows <= 96 || (int64_t)a.max_blocks_per_seq * a.block_size <= 1024;
+    if (rows <= 64) return 2 * units >= 3 * cus;
+    if (rows <= 96) return units >= 3 * cus;
+    return units >= 4 * cus && (int64_t)a.max_blocks_per_seq * a.block_size <= 2048;
 }
 }  // namespace
 

@@ -13,20 +13,23 @@
 // overlap with, and chaining items inside the workgroup only moves them around.  These shapes are
 // HBM-bound, not MFMA-bound -- so this kernel gives up the prefill kernel's software pipeline
 // (256 registers per wave, compiler-scheduled MFMA builtins, one score register set) to fit TWO
-// workgroups on a CU, and lets the hardware overlap one workgroup's fixed costs and softmax with
-// the other's streaming.
+// workgroups on a CU, and lets the hardware overlap one workgroup's fixed costs with the other's
+// streaming.
 //
 // Roofline: HBM.  Algorithmic bytes per unit (one cached token of one sequence) as in paged_attn.hip.
 //
-// Work decomposition: grid = num_seqs * Hkv workgroups (sequence fastest), 4 waves each; wave w owns
-// packed rows 32w .. 32w+31 of the kv head's R = T * G rows (row rho = token rho / G, head rho % G
-// of the group).  Key tiles of 64 tokens go HBM -> LDS by LDS-DMA exactly as in the prefill kernel
-// (wave w fetches block 4 tile + w of the sequence through a per-block buffer descriptor; the
-// bank-conflict swizzle is applied through each lane's source address), rings K x3 + V x2 = 80 KiB
-// per workgroup: step t requests V(t+1) and K(t+2); counted waits, two barriers per step.
+// Work decomposition: grid = num_seqs * Hkv workgroups (sequence fastest), 4 waves each; every wave
+// owns 32 of the kv head's R = T * G packed rows (row rho = token rho / G, head rho % G of the
+// group) -- which 32 is decided by the SIMD it landed on, see the kernel.  Key tiles of 64 tokens go
+// HBM -> LDS by LDS-DMA exactly as in the prefill kernel (wave w fetches block 4 tile + w of the
+// sequence through a per-block buffer descriptor; the bank-conflict swizzle is applied through each
+// lane's source address), rings K x3 + V x2 = 80 KiB per workgroup.
 // Per tile and wave: S^T = K Q^T (16 x mfma_f32_32x32x16_bf16, Q^T in registers), online softmax
 // in the exp2 domain with the query row on the lane, O^T += V^T P^T (16 MFMAs, V^T by
-// ds_read_b64_tr_b16, P^T straight from the S^T accumulators).
+// ds_read_b64_tr_b16, P^T straight from the S^T accumulators).  P.V runs one tile behind Q.K^T: step t
+// requests V(t) and K(t+2), computes S(t), then multiplies P(t-1) V(t-1) with the row maxima and the
+// exponentials of S(t) dealt out between its MFMAs (independent work for the wave's two pipes), and
+// rescales O afterwards; one counted wait and one barrier per step.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -52,7 +55,7 @@ constexpr int kKV = 64;                  // keys per tile
 constexpr int kRow = 256;                // bytes of a K / V row in LDS
 constexpr int kTile = kKV * kRow;        // 16 KiB
 constexpr int kWaves = 4;
-constexpr int kKRing = 3, kVRing = 2;    // K is requested two tiles ahead, V one
+constexpr int kKRing = 3, kVRing = 2;    // K is requested two tiles ahead; V(t) in step t, for step t+1's P.V
 constexpr int kVBase = kKRing * kTile;
 constexpr int kLds = (kKRing + kVRing) * kTile;  // 80 KiB: two workgroups fill a CU's 160 KiB
 constexpr int kORow = 272, kOStage = 32 * kORow;
@@ -98,14 +101,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         return (unsigned)table[bi];
     };
     unsigned id1 = block_id(1), id2 = block_id(2), id3 = block_id(3);  // the wave's blocks in tiles t+1, t+2, t+3
-
-    // this lane's query row
-    const int rho = 32 * wave + c;
-    const bool row_ok = rho < R;
-    const int t_row = row_ok ? rho / G : 0;
-    const int g_row = rho - t_row * G;
-    const int qpos = ctx - T + t_row;          // position: keys 0 .. qpos are visible
-    const bool wave_live = 32 * wave < R;      // (uniform)
 
     // ---- staging (see flash_attn_mfma.hip): piece j = rows 16 wave + 4 j .. + 3 of the tile, lane L
     // fetches the 16-byte chunk that the swizzle puts at position L & 15 of row L >> 4
@@ -163,6 +158,47 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         }
     };
 
+    unsigned id0 = block_id(0);
+    {
+        // K(0) and K(1); V(t) is requested in step t (P.V of tile t runs in step t+1).  V slot 1 is
+        // read by step 0's (empty) P.V: zeros
+        request_k(0, 0, id0);
+        request_k(1, 1, id1);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<u32x4 *>(lds + kVBase + kTile + (16 * wave + 4 * j) * kRow + 16 * lane) = z;
+    }
+
+    // Which 32 rows this wave owns.  With fewer than 97 rows some waves only fetch; a workgroup's four
+    // waves sit on the CU's four SIMDs in one of four rotations, so the computing waves of the two
+    // workgroups that share a CU meet on the same SIMDs as often as not.  Row block by SIMD instead:
+    // block (SIMD_ID + 2 TG_ID) & 3 -- TG_ID of HW_REG_HW_ID is the workgroup's slot on the CU, 0 or 1 for
+    // the two neighbours -- puts one workgroup's blocks 0, 1 on SIMDs 0, 1 and the other's on 2, 3.
+    // The waves agree through LDS (the third K slot is idle until step 0; the first tiles are on their
+    // way meanwhile) and fall back to block = wave unless their SIMD ids are four different ones: only
+    // the balance rests on the hardware's placement (scripts/diag/hwid_probe.hip shows it; K/V from L2,
+    // 256 x 2048 T = 16: 232 -> 208 us).
+    int rblk = wave;
+    {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        volatile unsigned *agree = reinterpret_cast<volatile unsigned *>(lds + 2 * kTile);
+        if (lane == 0) agree[wave] = (hw_id >> 4) & 3u;
+        __syncthreads();
+        const unsigned s0 = agree[0], s1 = agree[1], s2 = agree[2], s3 = agree[3];
+        __syncthreads();  // (read before step 0 requests K(2) into this slot)
+        const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 0xfu;
+        const int turned = (int)((((hw_id >> 4) & 3u) + 2u * ((hw_id >> 16) & 1u)) & 3u);
+        rblk = __builtin_amdgcn_readfirstlane(distinct ? turned : wave);
+    }
+    const int rho = 32 * rblk + c;
+    const bool row_ok = rho < R;
+    const int t_row = row_ok ? rho / G : 0;
+    const int g_row = rho - t_row * G;
+    const int qpos = ctx - T + t_row;          // position: keys 0 .. qpos are visible
+    const bool wave_live = 32 * rblk < R;      // (uniform)
+
     // ---- Q^T fragments (B operand of S^T = K Q^T): lane (c, h) holds Q[row c][16 ks + 8 h .. + 7]
     u32x4 qf[8];
     {
@@ -175,11 +211,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         for (int ks = 0; ks < 8; ++ks)
             qf[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 32u * ks), 0, 0));
     }
-    // "step -1": K(0), then V(0) and K(1) as every step requests V one and K two tiles ahead
-    request_k(0, 0, block_id(0));
-    request_v(0, 0, block_id(0));
-    request_k(1, 1, id1);
-
     // ---- LDS read addresses (as in flash_attn_mfma.hip)
     unsigned k_rd8[8];
 #pragma unroll
@@ -201,120 +232,182 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    // Counted waits (hipcc does not see the LDS-DMA requests): every step issues 4 V pieces, then 4 K
-    // pieces.  Before QK^T of tile t+1, K(t+1) must have landed -- everything younger (this step's 8
-    // pieces) may fly: vmcnt(8).  Before P.V of tile t, V(t) must have landed -- younger are K(t+1) and
-    // this step's 8: vmcnt(12).  Each wait is followed by a barrier (the pieces are the four waves').
     // (the Q rows are the only loads hipcc knows of: consumed here once, or it would wait for them --
     // and with them for every request in flight -- in front of each step's first MFMAs)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __syncthreads();
 
-    int kslot = 0, kslot_req = 2;  // K ring slot of tile t / of tile t+2
-    for (int t = 0; t < nt; ++t) {
-        const int vslot = t & 1;
-        request_v(t + 1, vslot ^ 1, id1);
-        request_k(t + 2, kslot_req, id2);
-        id1 = id2;
-        id2 = id3;
-        id3 = block_id(t + 4);
-        const unsigned char *kt = lds + kslot * kTile;
-        const unsigned char *vt = lds + kVBase + vslot * kTile;
-        kslot = kslot == kKRing - 1 ? 0 : kslot + 1;
-        kslot_req = kslot_req == kKRing - 1 ? 0 : kslot_req + 1;
-        u32x4 p[4];
-        if (wave_live) {
-            // ---- S^T = K Q^T: keys 0..31 of the tile in sa, 32..63 in sb.  The fragments of two
-            // k-steps are read while the two before them are multiplied (the order is pinned: left to
-            // itself hipcc puts every read right in front of its MFMA and waits for it there)
-            f32x16 sa, sb;
+    // ---- S^T = K Q^T of one tile: keys 0..31 in sa, 32..63 in sb.  The fragments of two k-steps are
+    // read while the two before them are multiplied (the order is pinned: left to itself hipcc puts
+    // every read right in front of its MFMA and waits for it there)
+    auto qk_tile = [&](const unsigned char *kt, f32x16 &sa, f32x16 &sb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sa[i] = 0.0f; sb[i] = 0.0f; }
-            u32x4 kf[2][4];  // [set][2 * (ks & 1) + key half]
-            auto read_k = [&](int set, int ks0) {
+        for (int i = 0; i < 16; ++i) { sa[i] = 0.0f; sb[i] = 0.0f; }
+        u32x4 kf[2][4];  // [set][2 * (ks & 1) + key half]
+        auto read_k = [&](int set, int ks0) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    kf[set][2 * i] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i]);
-                    kf[set][2 * i + 1] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i] + 32 * kRow);
-                }
-            };
-            read_k(0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) read_k((g + 1) & 1, 2 * g + 2);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i]),
-                                                                 __builtin_bit_cast(bf16x8, qf[2 * g + i]), sa, 0, 0, 0);
-                    sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i + 1]),
-                                                                 __builtin_bit_cast(bf16x8, qf[2 * g + i]), sb, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 2; ++i) {
+                kf[set][2 * i] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i]);
+                kf[set][2 * i + 1] = *reinterpret_cast<const u32x4 *>(kt + k_rd8[ks0 + i] + 32 * kRow);
             }
-            // ---- mask: only tiles that reach past the first query position or the context (a real
-            // branch: the asm statement keeps hipcc from turning it into 130 predicated instructions
-            // for every tile)
-            const int kv0 = t * kKV;
-            if (kv0 + kKV > ctx - T + 1) {
-                asm volatile("" ::: "memory");
+        };
+        read_k(0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    sa[r] = (key < ctx && key <= qpos) ? sa[r] : -INFINITY;
-                    sb[r] = (key + 32 < ctx && key + 32 <= qpos) ? sb[r] : -INFINITY;
-                }
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) read_k((g + 1) & 1, 2 * g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i]),
+                                                             __builtin_bit_cast(bf16x8, qf[2 * g + i]), sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[g & 1][2 * i + 1]),
+                                                             __builtin_bit_cast(bf16x8, qf[2 * g + i]), sb, 0, 0, 0);
             }
-            // ---- online softmax (exp2 domain); the row's two lane halves hold different keys
-            float mx = fmaxf(sa[0], sb[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_safe = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float mc = m_safe * scale_log2e;
-            if (__any(m_new > m_run)) {  // (uniform branch: most tiles leave every row's max alone)
-                const float alpha = fast_exp2(m_run * scale_log2e - mc);  // exp2(-inf) = 0 for a fresh row
-                l_run *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
-                m_run = m_new;
-            }
-            float psum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 32; e += 2) {
-                const float s0 = e < 16 ? sa[e & 15] : sb[e & 15];
-                const float s1 = e < 16 ? sa[(e + 1) & 15] : sb[(e + 1) & 15];
-                const float y0 = fast_exp2(__builtin_fmaf(s0, scale_log2e, -mc));
-                const float y1 = fast_exp2(__builtin_fmaf(s1, scale_log2e, -mc));
-                psum += y0 + y1;
-                p[e >> 3][(e & 7) >> 1] = pack_bf16x2(y0, y1);
-            }
-            l_run += psum;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // V(t) has landed (all four waves' pieces)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __syncthreads();
-        if (wave_live) {
-            // ---- O^T += V^T P^T, the four fragments of a d tile read while the d tile before is multiplied
-            s16x8 vf[2][4];
-            auto read_v = [&](int set, int dt) {
+    };
+    // ---- mask: only tiles that reach past the first query position or the context (a real branch:
+    // the asm statement keeps hipcc from turning it into 130 predicated instructions for every tile)
+    auto mask_tile = [&](int t, f32x16 &sa, f32x16 &sb) {
+        const int kv0 = t * kKV;
+        if (kv0 + kKV > ctx - T + 1) {
+            asm volatile("" ::: "memory");
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) {
-                    const unsigned char *p0 = vt + v_rd[dt] + sp * 16 * kRow;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kRow));
-                    vf[set][sp] = s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                sa[r] = (key < ctx && key <= qpos) ? sa[r] : -INFINITY;
+                sb[r] = (key + 32 < ctx && key + 32 <= qpos) ? sb[r] : -INFINITY;
+            }
+        }
+    };
+    auto row_max = [&](const f32x16 &sa, const f32x16 &sb) -> float {  // 15 v_max3 in two chains + 1
+        auto max3 = [](float a, float b, float c2) {
+            float r;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c2));
+            return r;
+        };
+        float ma = max3(sa[0], sa[1], sa[2]), mb = max3(sb[0], sb[1], sb[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) {
+            ma = max3(ma, sa[r], sa[r + 1]);
+            mb = max3(mb, sb[r], sb[r + 1]);
+        }
+        const float mx = max3(ma, mb, fmaxf(sa[15], sb[15]));
+        return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+    // the four V^T fragments of d tile dt
+    auto read_v = [&](const unsigned char *vt, s16x8 (&vf)[4], int dt) {
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const unsigned char *p0 = vt + v_rd[dt] + sp * 16 * kRow;
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 8 * kRow));
+            vf[sp] = s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        }
+    };
+    // p (bf16 pairs) of score elements e0 .. e0 + n - 1 (e < 16: sa, else sb), their sum added to psum
+    auto exp_n = [&](const f32x16 &sa, const f32x16 &sb, int e0, int n, float mc, u32x4 (&pd)[4], float &psum) {
+#pragma unroll
+        for (int e = e0; e < e0 + n; e += 2) {
+            const float s0 = e < 16 ? sa[e & 15] : sb[e & 15];
+            const float s1 = e < 16 ? sa[(e + 1) & 15] : sb[(e + 1) & 15];
+            const float y0 = fast_exp2(__builtin_fmaf(s0, scale_log2e, -mc));
+            const float y1 = fast_exp2(__builtin_fmaf(s1, scale_log2e, -mc));
+            psum += y0 + y1;
+            pd[e >> 3][(e & 7) >> 1] = pack_bf16x2(y0, y1);
+        }
+    };
+    auto rescale = [&](float m_new, float mc) {  // exp2(-inf) = 0 for a fresh row
+        const float alpha = fast_exp2(m_run * scale_log2e - mc);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
+        m_run = m_new;
+    };
+
+    {
+        // Step t: request V(t) and K(t+2); S = Q K(t)^T; then O += P(t-1) V(t-1), its MFMAs interleaved
+        // with the exponentials of S (independent work for the wave's two pipes); O is rescaled for
+        // tile t's maxima after that.  One wait + barrier per step: K(t+1) and V(t) have landed, the four
+        // pieces of K(t+2) may fly (vmcnt(4)), and every wave is done reading K(t) and V(t-1), whose slots
+        // the next step's requests overwrite.  K ring x3, V ring x2 as below.
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K(0) is in
+        __syncthreads();
+        u32x4 p[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // P^T of the tile before
+        int kslot = 0, kslot_req = 2;
+        for (int t = 0; t < nt; ++t) {
+            const int vslot = t & 1;
+            request_v(t, vslot, id0);
+            request_k(t + 2, kslot_req, id2);
+            id0 = id1;
+            id1 = id2;
+            id2 = id3;
+            id3 = block_id(t + 4);
+            const unsigned char *kt = lds + kslot * kTile;
+            const unsigned char *vt = lds + kVBase + (vslot ^ 1) * kTile;  // V(t-1)
+            kslot = kslot == kKRing - 1 ? 0 : kslot + 1;
+            kslot_req = kslot_req == kKRing - 1 ? 0 : kslot_req + 1;
+            if (wave_live) {
+                f32x16 sa, sb;
+                qk_tile(kt, sa, sb);
+                mask_tile(t, sa, sb);
+                // d tile 0 of P(t-1) V(t-1) under the row maxima of S, d tiles 1..3 under its exponentials
+                // (12 + 12 + 8 of the 32 scores a lane holds)
+                u32x4 pn[4];
+                float psum = 0.0f;
+                s16x8 vf[2][4];
+                read_v(vt, vf[0], 0);
+                read_v(vt, vf[1], 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[0][sp]),
+                                                                     __builtin_bit_cast(bf16x8, p[sp]), acc[0], 0, 0, 0);
+                float m_new = fmaxf(m_run, row_max(sa, sb));
+                asm volatile("" : "+v"(m_new));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
-            };
-            read_v(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const float mc = ((m_new == -INFINITY) ? 0.0f : m_new) * scale_log2e;
+#pragma unroll
+                for (int dt = 1; dt < 4; ++dt) {
+                    if (dt < 3) read_v(vt, vf[(dt + 1) & 1], dt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[dt & 1][sp]),
+                                                                          __builtin_bit_cast(bf16x8, p[sp]), acc[dt], 0, 0, 0);
+                    exp_n(sa, sb, 12 * (dt - 1), dt < 3 ? 12 : 8, mc, pn, psum);
+                    asm volatile("" : "+v"(psum));  // (here, not sunk below the rescale branch)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {  // one MFMA, then its share of the exponentials
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) asm volatile("" : "+v"(pn[sp]));
+                if (__any(m_new > m_run)) rescale(m_new, mc);  // (uniform branch: most tiles leave every row's max alone)
+                l_run += psum;
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) p[sp] = pn[sp];
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+        }
+        if (wave_live && nt > 0) {  // P.V of the last tile
+            const unsigned char *vt = lds + kVBase + ((nt - 1) & 1) * kTile;
+            s16x8 vf[2][4];
+            read_v(vt, vf[0], 0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                if (dt < 3) read_v((dt + 1) & 1, dt + 1);
+                if (dt < 3) read_v(vt, vf[(dt + 1) & 1], dt + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
@@ -323,9 +416,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // K(t+1) has landed
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue: O^T lane (c, h) holds O[row c][32 dt + 8 i + 4 h + (0..3)] in acc[dt][4 i .. 4 i + 3];
@@ -349,7 +439,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
     for (int r = 0; r < 8; ++r) {
         const int ri = 4 * r + (lane >> 4);
         const u32x4 x = *reinterpret_cast<const u32x4 *>(stg + ri * kORow + (lane & 15) * 16);
-        const int orho = 32 * wave + ri;
+        const int orho = 32 * rblk + ri;
         if (orho < R) {
             const int ot = orho / G, og = orho - ot * G;
             *reinterpret_cast<u32x4 *>(out + (((int64_t)seq * T + ot) * Hq + kvh * G + og) * kD + (lane & 15) * 8) = x;

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, '.')
 import nano_vllm_rs_amd as nv
 dev = torch.device('cuda:0')
-Hq, Hkv, D, bs = 32, 8, 128, 16
+Hq, Hkv, D, bs = int(os.environ.get('SWEEP_HQ', 32)), int(os.environ.get('SWEEP_HKV', 8)), 128, 16
 N, ctx = int(os.environ.get('SWEEP_N', 256)), int(os.environ.get('SWEEP_CTX', 2048))
 nblk = ctx // bs
 nb = N * nblk
@@ -24,9 +24,13 @@ def timeit(fn, iters=20, warm=3):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 Ts = [int(x) for x in os.environ.get('SWEEP_T', '1,4,8,9,12,13,16,24,32,36,48,64,96').split(',')]
-print('N', N, 'ctx', ctx, 'max_chunks', os.environ.get('NVLLM_PAGED_MAX_CHUNKS'), flush=True)
+print('N', N, 'ctx', ctx, 'Hq', Hq, 'Hkv', Hkv, 'max_chunks', os.environ.get('NVLLM_PAGED_MAX_CHUNKS'), flush=True)
+first = True
 for T in Ts:
     q = torch.randn((N, T, Hq, D), device=dev, dtype=torch.bfloat16)
+    if first:   # clocks and caches of a fresh process: the first entry used to read 5-10 % slow
+        timeit(lambda: nv.paged_attention_batched(q, kc, vc, bt, cl, 1 / math.sqrt(D)), iters=30)
+        first = False
     t = timeit(lambda: nv.paged_attention_batched(q, kc, vc, bt, cl, 1 / math.sqrt(D)))
     by = N * ctx * Hkv * D * 2 * 2
     print('T', T, 'rows/kvhead', T * Hq // Hkv, 'us', round(t, 1), 'GB/s of KV', round(by / t / 1e3, 1), flush=True)

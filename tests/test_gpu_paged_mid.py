@@ -3,8 +3,8 @@ workgroups per CU -- speculative verify with T > 12 and short prefill chunks ove
 
 Same contract and oracle as the other paged kernels (oracle.paged_attention restates reference
 src/attention/paged.rs:117-192; bottom-right causal mask :357-381).  The kernel is chosen by launch
-size (at least four (sequence, kv head) units per CU) and shape (up to 64 rows, or short contexts); the tests force it with
-NVLLM_PAGED_MID=1 on small launches and assert the path.  Cases: every group size the row packing
+size (from 1.5 (sequence, kv head) units per CU for up to 64 rows to 4 for 128 rows on contexts up to
+2048 tokens); the tests force it with NVLLM_PAGED_MID=1 on small launches and assert the path.  Cases: every group size the row packing
 sees (G = 1, 2, 4, 8 and a non-power-of-two 3), row counts at both ends of the range, every
 alignment of the context against the 64-key tiles and the 16-token blocks, contexts shorter than
 one tile, NaN in every slot no sequence owns, garbage ids behind a sequence's blocks.
@@ -61,11 +61,14 @@ def test_mid_kernel_agrees_with_the_prefill_kernel_and_is_chosen_by_size(dev, po
     path = lambda n, t, blocks=mb: nv.paged_attention_path(n, t, Hq, Hkv, D, bs, blocks, kc.shape[0])
     assert path(N, T) == "paged_mid"                   # 64 rows, enough units
     assert path(8, T) == "k1_paged"                    # too few units: the prefill kernel and its key split
+    assert path(48, T) == "paged_mid"                  # 1.5 units per CU: up to 64 rows
+    assert path(48, 24) == "k1_paged"                  # ... 96 rows want 3 units per CU
+    assert path(96, 24) == "paged_mid"
     assert path(N, 4) == "decode"                      # 16 rows
     assert path(N, 33) == "k1_paged"                   # 132 rows
     assert path(N, 24, 128) == "paged_mid"             # 96 rows
-    assert path(N, 28, 64) == "paged_mid"              # 112 rows, no context beyond 1024 tokens
-    assert path(N, 28, 128) == "k1_paged"              # 112 rows, long contexts
+    assert path(N, 32, 128) == "paged_mid"             # 128 rows, the most it takes, contexts up to 2048 tokens
+    assert path(N, 28, 129) == "k1_paged"              # 112 rows, longer contexts
     assert nv.capi.lib().nvllm_paged_attn_workspace_bytes(N, T, Hq, Hkv, D, bs, mb) == 0
     mid = _run(dev, q, kc, vc, tables, ctx_lens, scale)
     policy.setenv("NVLLM_PAGED_MID", 0)
