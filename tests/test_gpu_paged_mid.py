@@ -96,3 +96,35 @@ def test_mid_kernel_context_shorter_than_the_chunk_and_empty(dev, policy):
     d = np.abs(got - ref)
     assert d.max() <= 2e-2 and d.mean() <= 1e-3
     assert not got[0].any()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mid_kernel_random_shapes_against_the_prefill_kernel(dev, policy, seed):
+    # random group sizes, chunk lengths and contexts (empty, shorter than the chunk, one / two / many
+    # tiles, tile and block boundaries): the mid kernel against K1 over the cache on the same launch,
+    # and against the oracle on a sample of the sequences
+    rng = np.random.default_rng(9800 + seed)
+    D, bs = 128, 16
+    Hkv = int(rng.choice([1, 2, 4, 8]))
+    G = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    Hq = Hkv * G
+    T = int(rng.integers(-(-33 // G), 128 // G + 1))
+    edge = [0, 1, T - 1, T, T + 1, 63, 64, 65, 127, 128, 129, 16 * int(rng.integers(1, 40))]
+    ctx_lens = [max(int(c), 0) for c in edge] + [int(x) for x in rng.integers(1, 900, 12)]
+    kc, vc, tables = make_paged_case(rng, [max(c, 1) for c in ctx_lens], 1500, bs, Hkv, D, slack_blocks=1)
+    q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
+    scale = 1.0 / math.sqrt(D)
+    policy.setenv("NVLLM_PAGED_MID", 1)
+    assert nv.paged_attention_path(len(ctx_lens), T, Hq, Hkv, D, bs, max(len(t) for t in tables),
+                                   kc.shape[0]) == "paged_mid", (Hq, Hkv, T)
+    got = _run(dev, q, kc, vc, tables, ctx_lens, scale)
+    again = _run(dev, q, kc, vc, tables, ctx_lens, scale)
+    assert np.array_equal(got, again)                  # (the row assignment may differ from launch to launch: same bits)
+    policy.setenv("NVLLM_PAGED_MID", 0)
+    ref = _run(dev, q, kc, vc, tables, ctx_lens, scale)
+    assert np.isfinite(got).all()
+    d = np.abs(got - ref)
+    assert d.max() <= 2e-2 and d.mean() <= 1e-3, (Hq, Hkv, T, float(d.max()))
+    pick = [i for i, c in enumerate(ctx_lens) if c >= T][:6]
+    want = oracle_paged_batch(q[pick], kc, vc, [tables[i] for i in pick], [ctx_lens[i] for i in pick], bs, scale)
+    assert_attention_close(got[pick], want)

@@ -39,3 +39,38 @@ def test_k1_isa_audit(tmp_path):
         # the chained variants keep a few lane constants in scratch BETWEEN items (never inside the
         # step loops: asserted above); everything else does not spill at all
         assert n <= (24 if chained else 0), (name, n)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_mid_kernel_isa_audit(tmp_path):
+    """The mid kernel (paged_attn_mid.hip) lives on two workgroups per CU: at most 256 registers per
+    wave and exactly 80 KiB of LDS, no spill; its LDS-DMA statements are the only users of M0 and
+    each is `s_mov_b32 m0 / s_nop 0 / buffer_load ... lds` behind the s_nop that lets a VALU-written
+    descriptor settle; every loop iteration has exactly one barrier (P.V runs one tile behind)."""
+    import re
+    src = os.path.join(ROOT, "nano-vllm-rs_amd", "csrc", "paged_attn_mid.hip")
+    out = str(tmp_path / "mid.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17",
+                        "-I" + os.path.join(ROOT, "nano-vllm-rs_amd", "csrc"),
+                        "-I" + os.path.join(ROOT, "include"), "-x", "hip", "--cuda-device-only", "-S", src,
+                        "-o", out, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    usage = r.stderr
+    names = re.findall(r"Function Name: (\S+)", usage)
+    assert len(names) == 2 and all("paged_attn_mid_kernel" in n for n in names), names   # NT and plain
+    assert [int(x) for x in re.findall(r"VGPRs: (\d+)", usage)] and max(int(x) for x in re.findall(r"VGPRs: (\d+)", usage)) <= 256
+    assert set(re.findall(r"VGPRs Spill: (\d+)", usage)) == {"0"}
+    assert set(re.findall(r"SGPRs Spill: (\d+)", usage)) == {"0"}
+    assert set(re.findall(r"LDS Size \[bytes/block\]: (\d+)", usage)) == {"81920"}
+    assert set(re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", usage)) == {"0"}
+    lines = [l.strip() for l in open(out) if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    dma = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dwordx4") and l.endswith("lds")]
+    # per kernel: K(0), K(1) in the prologue + V and K in the loop = 4 requests x 4 pieces
+    assert len(dma) == 2 * 16, len(dma)
+    for i in dma:
+        assert lines[i - 1].startswith("s_nop 0") and lines[i - 2].startswith("s_mov_b32 m0") and \
+            lines[i - 3].startswith("s_nop 4"), lines[i - 3:i + 1]
+    m0 = [i for i, l in enumerate(lines) if re.search(r"\bm0\b", l)]
+    assert m0 == [i - 2 for i in dma], "M0 is touched outside the LDS-DMA statements"
+    nt = sum(" nt " in lines[i] or lines[i].endswith(" nt lds") for i in dma)
+    assert nt == 16                                  # the NT instantiation carries the hint on every request
