@@ -100,6 +100,17 @@ def test_noalloc_without_scratch_and_beyond_the_limit(dev):
     want = nv.paged_attention_batched(c["q"], c["kc"], c["vc"], c["bt"], c["cl"], SCALE)
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+    # a launch the mid kernel takes (48 sequences x 8 kv heads = 1.5 units per CU, 64 rows each): no
+    # scratch either, same kernel through both entries
+    m = _case(dev, 4, [100 + 13 * i for i in range(48)], 16, 2400)
+    assert nv.paged_attention_path(48, 16, Hq, Hkv, D, bs, m["bt"].shape[1], m["kc"].shape[0]) == "paged_mid"
+    out = torch.full((48, 16, Hq * D), float("nan"), dtype=torch.bfloat16, device=dev)
+    before = torch.cuda.memory_allocated(dev)
+    assert _noalloc(m, out) == 0, nv.capi.last_error()
+    assert torch.cuda.memory_allocated(dev) == before
+    want = nv.paged_attention_batched(m["q"], m["kc"], m["vc"], m["bt"], m["cl"], SCALE)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
     # more split-K scratch than the built-in array holds: refused, nothing launched
     limit = L.nvllm_paged_attn_noalloc_max_scratch_bytes()
     assert limit == 32 << 20
