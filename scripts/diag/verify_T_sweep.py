@@ -17,6 +17,8 @@ caches = [(torch.randn((pool, bs, Hkv, D), device=dev, dtype=torch.bfloat16),
            torch.randn((pool, bs, Hkv, D), device=dev, dtype=torch.bfloat16)) for _ in range(LAYERS)]
 kc, vc = caches[0]
 bt = torch.randperm(pool)[:nb].to(torch.int32).reshape(N, nblk).to(dev)
+if os.environ.get('SWEEP_SEQUENTIAL'):    # every sequence's blocks in ascending order, one sequence after the other
+    bt = torch.arange(nb, dtype=torch.int32).reshape(N, nblk).to(dev)
 if os.environ.get('SWEEP_HOT_BLOCKS'):   # every table entry among the first few blocks: K/V come from L2 (what is left is not HBM time)
     bt = bt % int(os.environ['SWEEP_HOT_BLOCKS'])
 cl = torch.full((N,), ctx, dtype=torch.int32, device=dev)
