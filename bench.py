@@ -181,9 +181,24 @@ def max_over_ranks(x, world, dev):
     return float(t.item())
 
 
+SETTLE_MS = 30.0   # untimed launches before the W warm-ups, see timed_loop
+
+
 def timed_loop(fn, steps, warmup, world, dev):
     """W warm-ups, then exactly K steps between barrier+synchronize pairs.
-    Returns (wall seconds max over ranks, mean per-launch ms from HIP events)."""
+    Returns (wall seconds max over ranks, mean per-launch ms from HIP events).
+    Before the W warm-ups the step runs untimed for about SETTLE_MS (at most 64 launches): every
+    case is built on the host first, the GPU idles meanwhile, and the first launches after that run
+    at ramping clocks (5-10 % slow for ~10-30 launches, profiles/r03 kernel trace) -- with a small W
+    (the driver's --steps 20 runs) the timed steps would measure the ramp, not the kernel."""
+    fn(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(1)
+    torch.cuda.synchronize()
+    one = max(max_over_ranks((time.perf_counter() - t0) * 1e3, world, dev), 1e-3)   # (the same count on every rank)
+    for i in range(min(64, int(SETTLE_MS / one))):
+        fn(2 + i)
     for i in range(warmup):
         fn(i)
     barrier(world)
@@ -615,6 +630,7 @@ def main(argv=None):
         warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True,
         scaling=res.get("scaling", "weak"),
         vs_baseline=None, dtype="bf16", data="synthetic", config=res["config"], roofline=res["roofline"],
+        untimed_settle_ms=SETTLE_MS,
         cpu_baseline=res.get("cpu_baseline"),
         device=dict(name=props.name, cus=props.multi_processor_count,
                     hbm_gib=round(props.total_memory / 2**30, 1),
