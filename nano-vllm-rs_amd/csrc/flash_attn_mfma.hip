@@ -809,20 +809,20 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             if (j < 4) {
                 if constexpr (NT)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory", "m0");
+                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
                 else
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory", "m0");
+                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
             } else {
                 const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
                 const int r = 4 * (j & 3) + (lane >> 4);
                 const unsigned off = r < rows_left ? dma_pv[j & 3] : kPgOutOfBlock;
                 if constexpr (NT)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                                 : : "s"(dst), "v"(off), "s"(rs) : "memory", "m0");
+                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
                 else
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                 : : "s"(dst), "v"(off), "s"(rs) : "memory", "m0");
+                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
             }
         } else {
             u32x4 rs = j < 4 ? dma_krs : dma_vrs;
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
             // within 5 wait states of a VALU write; a scalar instruction may
             unsigned so;
             asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, %4\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
-                         : "=&s"(so) : "s"(dst), "v"(j < 4 ? dma_kv[j] : dma_vv), "s"(rs), "s"(soff) : "memory", "m0");
+                         : "=&s"(so) : "s"(dst), "v"(j < 4 ? dma_kv[j] : dma_vv), "s"(rs), "s"(soff) : "memory");
         }
     };
 

@@ -135,10 +135,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
             unsigned dst = lds_base + (unsigned)(slot * kTile) + (16u * wave + 4u * j) * 256u;
             if constexpr (NT)
                 asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory", "m0");
+                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
             else
                 asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory", "m0");
+                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
         }
     };
     auto request_v = [&](int tile, int slot, unsigned id) {
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
             const unsigned off = r < rows_left ? dma_pv[j] : 0x40000000u;  // rows past the context: true zeros
             if constexpr (NT)
                 asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                             : : "s"(dst), "v"(off), "s"(rv) : "memory", "m0");
+                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
             else
                 asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(off), "s"(rv) : "memory", "m0");
+                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
         }
     };
 
