@@ -115,8 +115,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned r = 4u * j + rin;
-            dma_pk[j] = r * row_bytes + 16u * (pos ^ (r & 15u));
-            dma_pv[j] = r * row_bytes + 16u * (pos ^ (4u * rin));
+            dma_pk[j] = r * row_bytes + 16u * (pos ^ (r & 15u)) - 1024u * j;  // (r >= 4 j and a row has >= 256 bytes)
+            dma_pv[j] = r * row_bytes + 16u * (pos ^ (4u * rin)) - 1024u * j;
         }
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
@@ -127,35 +127,34 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         const unsigned long long a = base + (unsigned long long)id * block_bytes;
         return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, (live && id < num_cache_blocks) ? nrec : 0u, 0x00020000u};
     };
-    // this wave's 16 rows of K tile `tile` -> K ring slot `slot` (4 pieces) / of V tile -> V ring slot
+    // this wave's 16 rows of K tile `tile` -> K ring slot `slot` / of V tile -> V ring slot: four pieces
+    // of 1 KiB behind ONE write of M0 -- the instruction's immediate offset moves the LDS address and the
+    // memory address alike, so piece j's lane offset is stored less 1024 j (dma_pk / dma_pv below)
+#define NVLLM_MID_DMA4(NTBIT)                                                              \
+    "s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\t"                                          \
+    "buffer_load_dwordx4 %1, %5, 0 offen" NTBIT " lds\n\t"                                  \
+    "buffer_load_dwordx4 %2, %5, 0 offen offset:1024" NTBIT " lds\n\t"                      \
+    "buffer_load_dwordx4 %3, %5, 0 offen offset:2048" NTBIT " lds\n\t"                      \
+    "buffer_load_dwordx4 %4, %5, 0 offen offset:3072" NTBIT " lds"
+    auto request4 = [&](unsigned dst, unsigned o0, unsigned o1, unsigned o2, unsigned o3, const u32x4 &rs) {
+        if constexpr (NT)
+            asm volatile(NVLLM_MID_DMA4(" nt") : : "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs) : "memory");
+        else
+            asm volatile(NVLLM_MID_DMA4("") : : "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs) : "memory");
+    };
+#undef NVLLM_MID_DMA4
     auto request_k = [&](int tile, int slot, unsigned id) {
         const u32x4 rk = desc(kbase, id, tile < nt);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned dst = lds_base + (unsigned)(slot * kTile) + (16u * wave + 4u * j) * 256u;
-            if constexpr (NT)
-                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
-            else
-                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(dma_pk[j]), "s"(rk) : "memory");
-        }
+        request4(lds_base + (unsigned)(slot * kTile) + 16u * wave * 256u, dma_pk[0], dma_pk[1], dma_pk[2], dma_pk[3], rk);
     };
     auto request_v = [&](int tile, int slot, unsigned id) {
         const u32x4 rv = desc(vbase, id, tile < nt);
         const int rows_left = ctx - 16 * (4 * tile + wave);
+        unsigned off[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned dst = lds_base + (unsigned)(kVBase + slot * kTile) + (16u * wave + 4u * j) * 256u;
-            const int r = 4 * j + (lane >> 4);
-            const unsigned off = r < rows_left ? dma_pv[j] : 0x40000000u;  // rows past the context: true zeros
-            if constexpr (NT)
-                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
-            else
-                asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             : : "s"(dst), "v"(off), "s"(rv) : "memory");
-        }
+        for (int j = 0; j < 4; ++j)  // rows past the context: true zeros
+            off[j] = 4 * j + (lane >> 4) < rows_left ? dma_pv[j] : 0x40000000u;
+        request4(lds_base + (unsigned)(kVBase + slot * kTile) + 16u * wave * 256u, off[0], off[1], off[2], off[3], rv);
     };
 
     unsigned id0 = block_id(0);

@@ -45,8 +45,8 @@ def test_k1_isa_audit(tmp_path):
 def test_mid_kernel_isa_audit(tmp_path):
     """The mid kernel (paged_attn_mid.hip) lives on two workgroups per CU: at most 256 registers per
     wave and exactly 80 KiB of LDS, no spill; its LDS-DMA statements are the only users of M0 and
-    each is `s_mov_b32 m0 / s_nop 0 / buffer_load ... lds` behind the s_nop that lets a VALU-written
-    descriptor settle; every loop iteration has exactly one barrier (P.V runs one tile behind)."""
+    each is `s_mov_b32 m0 / s_nop 0 / 4 x buffer_load ... offset:1024 j lds` behind the s_nop that lets a
+    VALU-written descriptor settle; every loop iteration has exactly one barrier (P.V runs one tile behind)."""
     import re
     src = os.path.join(ROOT, "nano-vllm-rs_amd", "csrc", "paged_attn_mid.hip")
     out = str(tmp_path / "mid.s")
@@ -67,10 +67,14 @@ def test_mid_kernel_isa_audit(tmp_path):
     dma = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dwordx4") and l.endswith("lds")]
     # per kernel: K(0), K(1) in the prologue + V and K in the loop = 4 requests x 4 pieces
     assert len(dma) == 2 * 16, len(dma)
-    for i in dma:
-        assert lines[i - 1].startswith("s_nop 0") and lines[i - 2].startswith("s_mov_b32 m0") and \
-            lines[i - 3].startswith("s_nop 4"), lines[i - 3:i + 1]
+    # a request = one write of M0 and four pieces told apart by the immediate offset (which moves the LDS
+    # address and the memory address alike)
     m0 = [i for i, l in enumerate(lines) if re.search(r"\bm0\b", l)]
-    assert m0 == [i - 2 for i in dma], "M0 is touched outside the LDS-DMA statements"
+    assert len(m0) == len(dma) // 4 and all(lines[i].startswith("s_mov_b32 m0") for i in m0)
+    for i in m0:
+        assert lines[i - 1].startswith("s_nop 4") and lines[i + 1].startswith("s_nop 0"), lines[i - 1:i + 2]
+        assert [k for k in range(i + 2, i + 6)] == [k for k in dma if i < k < i + 6], lines[i:i + 6]
+        offs = [re.search(r"offset:(\d+)", lines[k]) for k in range(i + 2, i + 6)]
+        assert [int(o.group(1)) if o else 0 for o in offs] == [0, 1024, 2048, 3072]
     nt = sum(" nt " in lines[i] or lines[i].endswith(" nt lds") for i in dma)
     assert nt == 16                                  # the NT instantiation carries the hint on every request
