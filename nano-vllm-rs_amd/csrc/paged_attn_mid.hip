@@ -21,8 +21,9 @@
 // Work decomposition: grid = num_seqs * Hkv workgroups (sequence fastest), 4 waves each; every wave
 // owns 32 of the kv head's R = T * G packed rows (row rho = token rho / G, head rho % G of the
 // group) -- which 32 is decided by the SIMD it landed on, see the kernel.  Key tiles of 64 tokens go
-// HBM -> LDS by LDS-DMA exactly as in the prefill kernel (wave w fetches block 4 tile + w of the
-// sequence through a per-block buffer descriptor; the bank-conflict swizzle is applied through each
+// HBM -> LDS by LDS-DMA exactly as in the prefill kernel (block 4 tile + b of the sequence
+// through a per-block buffer descriptor, fetched by wave b when all four waves compute and by the
+// waves without rows otherwise; the bank-conflict swizzle is applied through each
 // lane's source address), rings K x3 + V x2 = 80 KiB per workgroup.
 // Per tile and wave: S^T = K Q^T (16 x mfma_f32_32x32x16_bf16, Q^T in registers), online softmax
 // in the exp2 domain with the query row on the lane, O^T += V^T P^T (16 MFMAs, V^T by
@@ -44,6 +45,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -95,13 +97,44 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
     ctx = ctx < 0 ? 0 : (ctx > cap ? cap : ctx);
     const int nt = (ctx + kKV - 1) / kKV;
     const int32_t *table = block_tables + (int64_t)seq * max_blocks_per_seq;
-    auto block_id = [&](int tile) -> unsigned {
-        int bi = 4 * tile + wave;
+    auto block_id = [&](int tile, int blk) -> unsigned {  // id of the sequence's block 4 tile + blk
+        int bi = 4 * tile + blk;
         bi = bi < max_blocks_per_seq ? bi : max_blocks_per_seq - 1;
         return (unsigned)table[bi];
     };
-    unsigned id1 = block_id(1), id2 = block_id(2), id3 = block_id(3);  // the wave's blocks in tiles t+1, t+2, t+3
 
+    // Which 32 rows this wave owns.  With fewer than 97 rows some waves only fetch; a workgroup's four
+    // waves sit on the CU's four SIMDs in one of four rotations, so the computing waves of the two
+    // workgroups that share a CU meet on the same SIMDs as often as not.  Row block by SIMD instead:
+    // block (SIMD_ID + 2 TG_ID) & 3 -- TG_ID of HW_REG_HW_ID is the workgroup's slot on the CU, 0 or 1 for
+    // the two neighbours -- puts one workgroup's blocks 0, 1 on SIMDs 0, 1 and the other's on 2, 3.
+    // The waves agree through LDS (the third K slot is idle until step 0) and fall back to block = wave unless their SIMD ids are four different ones: only
+    // the balance rests on the hardware's placement (scripts/diag/hwid_probe.hip shows it; K/V from L2,
+    // 256 x 2048 T = 16: 232 -> 208 us).
+    int rblk = wave;
+    {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        volatile unsigned *agree = reinterpret_cast<volatile unsigned *>(lds + 2 * kTile);
+        if (lane == 0) agree[wave] = (hw_id >> 4) & 3u;
+        __syncthreads();
+        const unsigned s0 = agree[0], s1 = agree[1], s2 = agree[2], s3 = agree[3];
+        __syncthreads();  // (read before step 0 requests K(2) into this slot)
+        const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 0xfu;
+        const int turned = (int)((((hw_id >> 4) & 3u) + 2u * ((hw_id >> 16) & 1u)) & 3u);
+        rblk = __builtin_amdgcn_readfirstlane(distinct ? turned : wave);
+    }
+    // Who fetches.  With 97..128 rows all four waves compute, and wave w fetches block w of every tile.
+    // With fewer, the waves without rows fetch EVERYTHING (two of them: blocks {0, 2} and {1, 3}; one:
+    // all four) and the computing waves issue no request at all: a wave stands still while its LDS-DMA
+    // requests wait for room among the CU's outstanding ones (700-1200 cycles per step in the stamps,
+    // profiles/r03_paged_mid_stamps.txt), which costs a fetch-only wave nothing.
+    const int n_live = (R + 31) >> 5;                    // waves with rows: 2, 3 or 4 (R >= 33)
+    const int n_idle = 4 - n_live;
+    const bool i_fetch = n_idle == 0 || rblk >= n_live;
+    const int blk0 = n_idle == 0 ? wave : rblk - n_live; // my first block, then every blk_step-th
+    const int blk_step = n_idle == 0 ? 4 : n_idle;
+    const int n_mine = !i_fetch ? 0 : (n_idle == 0 ? 1 : 4 / n_idle);   // 0, 1, 2 or 4 blocks per tile
     // ---- staging (see flash_attn_mfma.hip): piece j = rows 16 wave + 4 j .. + 3 of the tile, lane L
     // fetches the 16-byte chunk that the swizzle puts at position L & 15 of row L >> 4
     const unsigned row_bytes = (unsigned)(Hkv * kD * 2);
@@ -143,54 +176,54 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
             asm volatile(NVLLM_MID_DMA4("") : : "s"(dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs) : "memory");
     };
 #undef NVLLM_MID_DMA4
-    auto request_k = [&](int tile, int slot, unsigned id) {
+    auto request_k = [&](int tile, int slot, unsigned id, int blk) {
         const u32x4 rk = desc(kbase, id, tile < nt);
-        request4(lds_base + (unsigned)(slot * kTile) + 16u * wave * 256u, dma_pk[0], dma_pk[1], dma_pk[2], dma_pk[3], rk);
+        request4(lds_base + (unsigned)(slot * kTile) + 16u * blk * 256u, dma_pk[0], dma_pk[1], dma_pk[2], dma_pk[3], rk);
     };
-    auto request_v = [&](int tile, int slot, unsigned id) {
+    auto request_v = [&](int tile, int slot, unsigned id, int blk) {
         const u32x4 rv = desc(vbase, id, tile < nt);
-        const int rows_left = ctx - 16 * (4 * tile + wave);
+        const int rows_left = ctx - 16 * (4 * tile + blk);
         unsigned off[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)  // rows past the context: true zeros
             off[j] = 4 * j + (lane >> 4) < rows_left ? dma_pv[j] : 0x40000000u;
-        request4(lds_base + (unsigned)(kVBase + slot * kTile) + 16u * wave * 256u, off[0], off[1], off[2], off[3], rv);
+        request4(lds_base + (unsigned)(kVBase + slot * kTile) + 16u * blk * 256u, off[0], off[1], off[2], off[3], rv);
+    };
+    // Counted waits: what may still fly is this wave's LAST request group, four pieces per block it fetches
+    auto wait_all_but_last_group = [&]() {
+        if (n_mine == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n_mine == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n_mine == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
 
-    unsigned id0 = block_id(0);
+    // ids of my blocks in tiles t .. t+3 (slot k = my k-th block)
+    unsigned id0[4], id1[4], id2[4], id3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        id0[k] = id1[k] = id2[k] = id3[k] = 0u;
+        if (k < n_mine) {
+            const int blk = blk0 + k * blk_step;
+            id0[k] = block_id(0, blk);
+            id1[k] = block_id(1, blk);
+            id2[k] = block_id(2, blk);
+            id3[k] = block_id(3, blk);
+        }
+    }
     {
         // K(0) and K(1); V(t) is requested in step t (P.V of tile t runs in step t+1).  V slot 1 is
         // read by step 0's (empty) P.V: zeros
-        request_k(0, 0, id0);
-        request_k(1, 1, id1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n_mine) request_k(0, 0, id0[k], blk0 + k * blk_step);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n_mine) request_k(1, 1, id1[k], blk0 + k * blk_step);
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<u32x4 *>(lds + kVBase + kTile + (16 * wave + 4 * j) * kRow + 16 * lane) = z;
     }
 
-    // Which 32 rows this wave owns.  With fewer than 97 rows some waves only fetch; a workgroup's four
-    // waves sit on the CU's four SIMDs in one of four rotations, so the computing waves of the two
-    // workgroups that share a CU meet on the same SIMDs as often as not.  Row block by SIMD instead:
-    // block (SIMD_ID + 2 TG_ID) & 3 -- TG_ID of HW_REG_HW_ID is the workgroup's slot on the CU, 0 or 1 for
-    // the two neighbours -- puts one workgroup's blocks 0, 1 on SIMDs 0, 1 and the other's on 2, 3.
-    // The waves agree through LDS (the third K slot is idle until step 0; the first tiles are on their
-    // way meanwhile) and fall back to block = wave unless their SIMD ids are four different ones: only
-    // the balance rests on the hardware's placement (scripts/diag/hwid_probe.hip shows it; K/V from L2,
-    // 256 x 2048 T = 16: 232 -> 208 us).
-    int rblk = wave;
-    {
-        unsigned hw_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        volatile unsigned *agree = reinterpret_cast<volatile unsigned *>(lds + 2 * kTile);
-        if (lane == 0) agree[wave] = (hw_id >> 4) & 3u;
-        __syncthreads();
-        const unsigned s0 = agree[0], s1 = agree[1], s2 = agree[2], s3 = agree[3];
-        __syncthreads();  // (read before step 0 requests K(2) into this slot)
-        const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 0xfu;
-        const int turned = (int)((((hw_id >> 4) & 3u) + 2u * ((hw_id >> 16) & 1u)) & 3u);
-        rblk = __builtin_amdgcn_readfirstlane(distinct ? turned : wave);
-    }
     const int rho = 32 * rblk + c;
     const bool row_ok = rho < R;
     const int t_row = row_ok ? rho / G : 0;
@@ -292,7 +325,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
             mb = max3(mb, sb[r], sb[r + 1]);
         }
         const float mx = max3(ma, mb, fmaxf(sa[15], sb[15]));
-        return fmaxf(mx, __shfl_xor(mx, 32));
+        // the other lane half's maximum: v_permlane32_swap (hipcc's __shfl_xor goes through LDS, a round
+        // trip the exponentials would wait for); s_nop 1 = the VALU-write -> permlane wait states
+        float a = mx, b2 = mx;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+        return fmaxf(a, b2);
     };
     // the four V^T fragments of d tile dt
     auto read_v = [&](const unsigned char *vt, s16x8 (&vf)[4], int dt) {
@@ -305,15 +342,16 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         }
     };
     // p (bf16 pairs) of score elements e0 .. e0 + n - 1 (e < 16: sa, else sb), their sum added to psum
-    auto exp_n = [&](const f32x16 &sa, const f32x16 &sb, int e0, int n, float mc, u32x4 (&pd)[4], float &psum) {
+    auto exp_n = [&](const f32x16 &sa, const f32x16 &sb, int e0, int n, float mc, u32x4 (&pd)[4], f32x2 &psum2) {
+        // (two scores at a time: the scale-and-shift and the row sum as packed f32 instructions)
+        const f32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {-mc, -mc};
 #pragma unroll
         for (int e = e0; e < e0 + n; e += 2) {
-            const float s0 = e < 16 ? sa[e & 15] : sb[e & 15];
-            const float s1 = e < 16 ? sa[(e + 1) & 15] : sb[(e + 1) & 15];
-            const float y0 = fast_exp2(__builtin_fmaf(s0, scale_log2e, -mc));
-            const float y1 = fast_exp2(__builtin_fmaf(s1, scale_log2e, -mc));
-            psum += y0 + y1;
-            pd[e >> 3][(e & 7) >> 1] = pack_bf16x2(y0, y1);
+            const f32x2 s2 = {e < 16 ? sa[e & 15] : sb[e & 15], e < 16 ? sa[(e + 1) & 15] : sb[(e + 1) & 15]};
+            const f32x2 x2 = __builtin_elementwise_fma(s2, sc2, mc2);
+            const f32x2 y2 = {fast_exp2(x2[0]), fast_exp2(x2[1])};
+            psum2 += y2;
+            pd[e >> 3][(e & 7) >> 1] = pack_bf16x2(y2[0], y2[1]);
         }
     };
     auto rescale = [&](float m_new, float mc) {  // exp2(-inf) = 0 for a fresh row
@@ -329,21 +367,27 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
     {
         // Step t: request V(t) and K(t+2); S = Q K(t)^T; then O += P(t-1) V(t-1), its MFMAs interleaved
         // with the exponentials of S (independent work for the wave's two pipes); O is rescaled for
-        // tile t's maxima after that.  One wait + barrier per step: K(t+1) and V(t) have landed, the four
-        // pieces of K(t+2) may fly (vmcnt(4)), and every wave is done reading K(t) and V(t-1), whose slots
-        // the next step's requests overwrite.  K ring x3, V ring x2 as below.
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K(0) is in
+        // tile t's maxima after that.  One wait + barrier per step: K(t+1) and V(t) have landed, the
+        // pieces of K(t+2) may fly (four per block the wave fetches), and every wave is done reading K(t) and V(t-1), whose slots
+        // the next step's requests overwrite.  K ring x3, V ring x2.
+        wait_all_but_last_group();  // K(0) is in
         __syncthreads();
         u32x4 p[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // P^T of the tile before
         int kslot = 0, kslot_req = 2;
         for (int t = 0; t < nt; ++t) {
             const int vslot = t & 1;
-            request_v(t, vslot, id0);
-            request_k(t + 2, kslot_req, id2);
-            id0 = id1;
-            id1 = id2;
-            id2 = id3;
-            id3 = block_id(t + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_mine) request_v(t, vslot, id0[k], blk0 + k * blk_step);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_mine) {
+                    request_k(t + 2, kslot_req, id2[k], blk0 + k * blk_step);
+                    id0[k] = id1[k];
+                    id1[k] = id2[k];
+                    id2[k] = id3[k];
+                    id3[k] = block_id(t + 4, blk0 + k * blk_step);
+                }
             const unsigned char *kt = lds + kslot * kTile;
             const unsigned char *vt = lds + kVBase + (vslot ^ 1) * kTile;  // V(t-1)
             kslot = kslot == kKRing - 1 ? 0 : kslot + 1;
@@ -355,7 +399,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
                 // d tile 0 of P(t-1) V(t-1) under the row maxima of S, d tiles 1..3 under its exponentials
                 // (12 + 12 + 8 of the 32 scores a lane holds)
                 u32x4 pn[4];
-                float psum = 0.0f;
+                f32x2 psum = {0.0f, 0.0f};
                 s16x8 vf[2][4];
                 read_v(vt, vf[0], 0);
                 read_v(vt, vf[1], 1);
@@ -393,11 +437,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp) asm volatile("" : "+v"(pn[sp]));
                 if (__any(m_new > m_run)) rescale(m_new, mc);  // (uniform branch: most tiles leave every row's max alone)
-                l_run += psum;
+                l_run += psum[0] + psum[1];
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp) p[sp] = pn[sp];
             }
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            wait_all_but_last_group();
             __syncthreads();
         }
         if (wave_live && nt > 0) {  // P.V of the last tile

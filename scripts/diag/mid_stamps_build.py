@@ -25,8 +25,8 @@ rep('''    const int tid = threadIdx.x;
     asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
     const int tid = threadIdx.x;
     const int lane = tid & 63;''')
-rep('''        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K(0) is in
-        __syncthreads();''', '''        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K(0) is in
+rep('''        wait_all_but_last_group();  // K(0) is in
+        __syncthreads();''', '''        wait_all_but_last_group();  // K(0) is in
         __syncthreads();
         MID_STAMP(4);''')
 rep('''            if (wave_live) {
@@ -41,12 +41,12 @@ rep('''                mask_tile(t, sa, sb);
                 // d tile 0''')
 rep('''                for (int sp = 0; sp < 4; ++sp) p[sp] = pn[sp];
             }
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            wait_all_but_last_group();
             __syncthreads();
         }''', '''                for (int sp = 0; sp < 4; ++sp) p[sp] = pn[sp];
                 MID_STAMP(2);
             }
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            wait_all_but_last_group();
             MID_STAMP(3);
             __syncthreads();
             MID_STAMP(6);
