@@ -261,7 +261,7 @@ int64_t nvllm_kv_cache_total_bytes(int64_t num_blocks, int64_t block_size, int64
  * NVLLM_PAGED_MAX_ROWS, NVLLM_PAGED_SPLITS, NVLLM_PAGED_WAVE_TARGET,
  * NVLLM_PAGED_NT, NVLLM_PAGED_HPB, NVLLM_PAGED_FLASH, NVLLM_K1_PAIRING (0
  * balanced / 1 adjacent), NVLLM_K1_PACK, NVLLM_K1_KSPLIT, NVLLM_K1_CHAIN, NVLLM_PAGED_MID (0 never / 1 whenever the
- * shape allows / -1 by launch size).  Environment variables
+ * shape allows / -1 by launch size / 2 as 1 with its rows by wave index, a test hook).  Environment variables
  * of the same names seed the values once, at first use; no launch reads the
  * environment.  Process-wide: nvllm_paged_attn_workspace_bytes and the launch
  * both see the value in force when they are called.  _reset restores the

@@ -26,7 +26,8 @@ struct LaunchPolicy {
     int k1_pairing;         // NVLLM_K1_PAIRING: 0 balanced ('b'), 1 adjacent ('a'), -1 by grid size
     int k1_pack;            // NVLLM_K1_PACK: 0 no head packing, -1 / 1 pack when the group allows
     int k1_ksplit;          // NVLLM_K1_KSPLIT: > 0 forces the key-split part count
-    int paged_mid;          // NVLLM_PAGED_MID: 0 never / 1 whenever supported / -1 by launch size (paged_attn_mid.hip)
+    int paged_mid;          // NVLLM_PAGED_MID: 0 never / 1 whenever supported / -1 by launch size (paged_attn_mid.hip);
+                            // 2 = as 1 with rows by wave index instead of by SIMD (the kernel's fallback, for tests)
     int k1_chain;           // NVLLM_K1_CHAIN: items per workgroup (0 / 1 = no chaining), -1 by grid size
 };
 // a snapshot by value (each field read atomically).  A workspace query and the launch it sizes see

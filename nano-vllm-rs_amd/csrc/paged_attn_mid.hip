@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
     const __bf16 *__restrict__ q, const unsigned char *__restrict__ k_cache,
     const unsigned char *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
     const int32_t *__restrict__ context_lens, __bf16 *__restrict__ out, int T, int Hq, int Hkv,
-    int max_blocks_per_seq, unsigned num_cache_blocks, float scale_log2e) {
+    int max_blocks_per_seq, unsigned num_cache_blocks, float scale_log2e, int by_simd) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void paged_attn_mid_kernel(
         __syncthreads();  // (read before step 0 requests K(2) into this slot)
         const bool distinct = ((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)) == 0xfu;
         const int turned = (int)((((hw_id >> 4) & 3u) + 2u * ((hw_id >> 16) & 1u)) & 3u);
-        rblk = __builtin_amdgcn_readfirstlane(distinct ? turned : wave);
+        rblk = __builtin_amdgcn_readfirstlane((distinct && by_simd) ? turned : wave);  // (by_simd = 0: the fallback, for tests)
     }
     // Who fetches.  With 97..128 rows all four waves compute, and wave w fetches block w of every tile.
     // With fewer, the waves without rows fetch EVERYTHING (two of them: blocks {0, 2} and {1, 3}; one:
@@ -521,7 +521,7 @@ hipError_t launch_paged_attn_mid(const PagedAttnArgs &a, hipStream_t stream) {
         static_cast<const __bf16 *>(a.q), static_cast<const unsigned char *>(a.k_cache),
         static_cast<const unsigned char *>(a.v_cache), a.block_tables, a.context_lens,
         static_cast<__bf16 *>(a.out), a.num_new_tokens, a.num_heads, a.num_kv_heads, a.max_blocks_per_seq,
-        (unsigned)a.num_cache_blocks, a.scale * 1.4426950408889634f);
+        (unsigned)a.num_cache_blocks, a.scale * 1.4426950408889634f, launch_policy().paged_mid == 2 ? 0 : 1);
     return hipGetLastError();
 }
 

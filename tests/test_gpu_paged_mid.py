@@ -128,3 +128,23 @@ def test_mid_kernel_random_shapes_against_the_prefill_kernel(dev, policy, seed):
     pick = [i for i, c in enumerate(ctx_lens) if c >= T][:6]
     want = oracle_paged_batch(q[pick], kc, vc, [tables[i] for i in pick], [ctx_lens[i] for i in pick], bs, scale)
     assert_attention_close(got[pick], want)
+
+
+@pytest.mark.parametrize("T", [13, 16, 24, 32])
+def test_rows_by_simd_and_rows_by_wave_give_the_same_bits(dev, policy, T):
+    # which wave computes (and which waves fetch) a kv head's rows is decided by where the hardware put the
+    # waves; NVLLM_PAGED_MID=2 takes the kernel's fallback (row block = wave index) -- every row's arithmetic
+    # is the same instruction sequence either way, so the outputs must be identical
+    Hq, Hkv, D, bs = 32, 8, 128, 16
+    rng = np.random.default_rng(9900 + T)
+    ctx_lens = [T + int(x) for x in rng.integers(0, 600, 40)]
+    kc, vc, tables = make_paged_case(rng, ctx_lens, 1700, bs, Hkv, D, slack_blocks=1)
+    q = bf16_randn(rng, (len(ctx_lens), T, Hq, D))
+    scale = 1.0 / math.sqrt(D)
+    policy.setenv("NVLLM_PAGED_MID", 1)
+    a = _run(dev, q, kc, vc, tables, ctx_lens, scale)
+    policy.setenv("NVLLM_PAGED_MID", 2)
+    assert nv.paged_attention_path(len(ctx_lens), T, Hq, Hkv, D, bs, max(len(t) for t in tables),
+                                   kc.shape[0]) == "paged_mid"
+    b = _run(dev, q, kc, vc, tables, ctx_lens, scale)
+    assert np.array_equal(a, b)
