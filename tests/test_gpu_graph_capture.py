@@ -89,3 +89,40 @@ def test_decode_steps_replayed_from_a_graph_match_eager(dev, N, ctx0):
         torch.cuda.synchronize()
         for got, ref in zip(outs, want[s]):
             assert torch.equal(got, ref), (s,)
+
+
+def test_verify_launch_of_the_mid_kernel_replayed_from_a_graph(dev):
+    """Speculative verify (T = 16 new tokens of 48 sequences: the mid kernel, paged_attn_mid.hip)
+    captured once and replayed while context_lens advance on the device: the kernel reads lengths
+    and tables only on the device, decides which wave computes which rows from hardware registers,
+    and uses no workspace -- replays must equal eager launches bit for bit."""
+    Hq, Hkv, D, bs, N, T = 32, 8, 128, 16, 48, 16
+    max_blocks = 24
+    nb = N * max_blocks
+    scale = 1.0 / math.sqrt(D)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randn(s, generator=g).to(dev, torch.bfloat16)
+    kc, vc = rnd(nb, bs, Hkv, D), rnd(nb, bs, Hkv, D)
+    bt = torch.randperm(nb, generator=g).to(torch.int32).reshape(N, max_blocks).to(dev)
+    assert nv.paged_attention_path(N, T, Hq, Hkv, D, bs, max_blocks, nb) == "paged_mid"
+    q = rnd(N, T, Hq, D)
+    lens = [torch.randint(T, max_blocks * bs, (N,), generator=g, dtype=torch.int32).to(dev) for _ in range(4)]
+    want = []
+    for cl in lens:
+        want.append(nv.paged_attention_batched(q, kc, vc, bt, cl, scale).clone())
+    torch.cuda.synchronize()
+    scl = lens[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up outside capture
+        nv.paged_attention_batched(q, kc, vc, bt, scl, scale)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):                      # (the output lives in the graph's memory pool)
+        out = nv.paged_attention_batched(q, kc, vc, bt, scl, scale)
+    for cl, w in zip(lens, want):
+        scl.copy_(cl)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, w)
