@@ -799,41 +799,56 @@ __global__ __launch_bounds__(64 * kWaves, 1) void flash_attn_mfma_kernel(
     // write of an SGPR, which a buffer instruction may read only 5 wait states later; hipcc does not
     // look into the asm statement): one s_nop 4 between.  For the pieces issued outside the
     // hand-scheduled bodies, whose operands are long in place (scripts/k1_lab/check_asm.py audits both).
+    // The four pieces of a request go behind ONE write of M0 (27 -> 13.5 cycles of issue per piece on
+    // an idle queue, scripts/diag/ldsdma_issue.hip; -1.2 % dense, -1.4...-2.7 % over the cache): piece
+    // j & 3 carries the immediate offset 1024 (j & 3), which moves the LDS address and the memory
+    // address alike; the memory side is set right through the scalar offset (dense) or the lane offset
+    // (paged).  The pieces of a request are always issued in order with no other request in between
+    // (check_asm.py audits that too).
     auto dma_piece = [&](int t, int kslot, int vslot, int j, unsigned sid = 0u, bool settle = false) {
-        const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)(j & 3);
-        unsigned soff = ((unsigned)t * kKV + r0) * row_bytes;
-        unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + r0 * 256u;
+        const int jj = j & 3;
+        const unsigned r0 = 16u * (unsigned)wave + 4u * (unsigned)jj;
+        unsigned dst = lds_base + (j < 4 ? (unsigned)(kKBase + kslot * kKTile) : (unsigned)(vslot * kVTile)) + 16u * (unsigned)wave * 256u;
         if constexpr (PAGED) {
             u32x4 rs = pg_desc(j < 4 ? pg_kbase : pg_vbase, sid);
             if (settle) asm volatile("s_nop 4" : "+s"(dst));
-            if (j < 4) {
-                if constexpr (NT)
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                 : : "s"(dst), "v"(dma_pk[j]), "s"(rs) : "memory");
-            } else {
+            unsigned off;
+            if (j < 4) off = dma_pk[jj] - 1024u * jj;
+            else {
                 const int rows_left = Skv - 16 * (4 * (t + tile0) + wave);
-                const int r = 4 * (j & 3) + (lane >> 4);
-                const unsigned off = r < rows_left ? dma_pv[j & 3] : kPgOutOfBlock;
-                if constexpr (NT)
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
-                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                 : : "s"(dst), "v"(off), "s"(rs) : "memory");
+                const int r = 4 * jj + (lane >> 4);
+                off = r < rows_left ? dma_pv[jj] - 1024u * jj : kPgOutOfBlock;
             }
+#define K1_PG_PIECE(OFFS, NTS)                                                                                     \
+    asm volatile("buffer_load_dwordx4 %0, %1, 0 offen" OFFS NTS " lds" : : "v"(off), "s"(rs) : "memory")
+            if (jj == 0) {
+                if constexpr (NT)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" : : "s"(dst), "v"(off), "s"(rs) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(off), "s"(rs) : "memory");
+            } else if (jj == 1) {
+                if constexpr (NT) K1_PG_PIECE(" offset:1024", " nt"); else K1_PG_PIECE(" offset:1024", "");
+            } else if (jj == 2) {
+                if constexpr (NT) K1_PG_PIECE(" offset:2048", " nt"); else K1_PG_PIECE(" offset:2048", "");
+            } else {
+                if constexpr (NT) K1_PG_PIECE(" offset:3072", " nt"); else K1_PG_PIECE(" offset:3072", "");
+            }
+#undef K1_PG_PIECE
         } else {
             u32x4 rs = j < 4 ? dma_krs : dma_vrs;
+            unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)t * kKV + r0) * row_bytes - 1024u * jj));   // (a row has >= 256 bytes)
             if (settle) asm volatile("s_nop 4" : "+s"(dst), "+s"(rs), "+s"(soff));
-            // the tile offset goes through a scalar move (which is also the wait state between the
-            // write of M0 and the load): under register pressure hipcc brings it back from a spill
-            // lane right in front of the statement, and a buffer instruction must not read an SGPR
-            // within 5 wait states of a VALU write; a scalar instruction may
             unsigned so;
-            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, %4\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
-                         : "=&s"(so) : "s"(dst), "v"(j < 4 ? dma_kv[j] : dma_vv), "s"(rs), "s"(soff) : "memory");
+            const unsigned vo = j < 4 ? dma_kv[jj] : dma_vv;
+            if (jj == 0)
+                asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, %4\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
+                             : "=&s"(so) : "s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+            else if (jj == 1)
+                asm volatile("s_mov_b32 %0, %3\n\tbuffer_load_dwordx4 %1, %2, %0 offen offset:1024 lds" : "=&s"(so) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+            else if (jj == 2)
+                asm volatile("s_mov_b32 %0, %3\n\tbuffer_load_dwordx4 %1, %2, %0 offen offset:2048 lds" : "=&s"(so) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, %3\n\tbuffer_load_dwordx4 %1, %2, %0 offen offset:3072 lds" : "=&s"(so) : "v"(vo), "s"(rs), "s"(soff) : "memory");
         }
     };
 

@@ -46,13 +46,24 @@ for n, l in enumerate(lines, 1):
     elif ';;#ASMEND' in l or '; ;#ASMEND' in l: inasm = False
     elif re.search(r'\bm0\b', l) and not l.strip().startswith(';') and not inasm:
         m0bad.append((n, l.strip()))
+# A request = four 1 KiB pieces behind ONE write of M0: the first piece's statement writes M0 right in
+# front of its load (one wait state between: s_nop 0, or the scalar move that carries the tile offset), the
+# other three carry the immediate offsets 1024, 2048, 3072 (which move the LDS address and the memory
+# address alike) and must follow their first piece in that order with no other write of M0 in between.
+prev_off = None
 for k, (n, l) in enumerate(code):
+    if l.startswith('s_mov_b32 m0,'): prev_off = 'm0'
     if re.search(r'buffer_load.* lds$', l):
         dmas += 1
-        # ... followed by one wait state: s_nop 0, or the scalar move that carries the tile offset
-        if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or not (
-                code[k - 1][1] == 's_nop 0' or re.match(r's_mov_b32 s\d+, s\d+$', code[k - 1][1])):
+        mo = re.search(r'offset:(\d+)', l)
+        off = int(mo.group(1)) if mo else 0
+        if off == 0:
+            if k < 2 or not code[k - 2][1].startswith('s_mov_b32 m0,') or not (
+                    code[k - 1][1] == 's_nop 0' or re.match(r's_mov_b32 s\d+, s\d+$', code[k - 1][1])):
+                m0bad.append((n, l))
+        elif off not in (1024, 2048, 3072) or prev_off != off - 1024:
             m0bad.append((n, l))
+        prev_off = off
 # VALU write of an SGPR -> VMEM read of it needs 5 wait states; hipcc pads its own instructions,
 # not the inside of an asm statement (which starts with s_mov m0 + s_nop 0 = 2 states)
 def sregs(tok):
